@@ -1,0 +1,194 @@
+/*
+ * nint.h -- C ABI of the MI355X-native ConvLSTM hot path for Smart-NINT (nasa-niswan).
+ *
+ * The reference (smhassanerfani/nasa-niswan) has NO native/FFI interface: its boundary for
+ * this path is the Python surface `model.py:ConvLSTMCell/ConvLSTM` + the `train.py` batch
+ * step.  This header is the boundary the drop-in Python modules in `nasa-niswan_amd/` bind
+ * with ctypes; every entry point cites the reference lines whose ATen op sequence it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the parameter says "host".
+ *   - every entry takes an explicit `stream` (hipStream_t as void*) and never synchronises.
+ *   - every entry returns 0 on success, a negative NINT_E_* code for bad arguments or a
+ *     positive hipError_t value; nothing throws or aborts.
+ *   - the caller owns all memory (the Python side allocates through torch's caching
+ *     allocator); the library keeps no state between calls.
+ *
+ * Internal data layout ("slabs"), chosen for gfx950 rather than inherited from NCHW:
+ *   halo slab     ET [N][Hh][Wh][Cp]   channels-last, ET = float or bf16, physical zero halo P
+ *                                      on every side plus zero slack up to a multiple of 8 rows /
+ *                                      32 columns, Cp = channels rounded up to KC (16 f32 / 32 bf16)
+ *   compact slab  f32 [N][H][W][Cp]    channels-last, no halo (cell state c, dh, dc)
+ *   gate stash    ET [N][H][W][Gc]     Gc = 4*Ch16, column n' = (cblock*4 + gate)*16 + col
+ *   image index   n = t*B + b          (time-major so that one launch can span all T)
+ */
+#ifndef NINT_H
+#define NINT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NINT_VERSION 100
+
+enum { NINT_F32 = 0, NINT_BF16 = 1 };
+
+enum {
+  NINT_OK = 0,
+  NINT_E_ARG = -1,      /* inconsistent / unsupported argument */
+  NINT_E_SHAPE = -2,    /* shape not supported by any kernel instantiation */
+  NINT_E_LDS = -3,      /* tile does not fit in the 160 KiB LDS */
+  NINT_E_ALIGN = -4     /* pointer not 16-byte aligned */
+};
+
+/* Spatial geometry shared by all slabs of one model instance. */
+typedef struct nint_geom {
+  int32_t H, W;    /* grid the model runs on (100x154 = 90x144 + halo 5 in the reference, launcher.sh:24) */
+  int32_t P;       /* physical zero halo of halo slabs = max_l(k_l/2) */
+  int32_t Hh, Wh;  /* halo-slab rows / cols: roundup(H,8)+2P, roundup(W,32)+2P */
+} nint_geom;
+
+/* One ConvLSTMCell (reference model.py:196-231) in packed form. */
+typedef struct nint_layer {
+  int32_t Cx, Cxp;        /* input channels / padded to KC */
+  int32_t Ch, Ch16, Chp;  /* hidden channels / padded to 16 / padded to KC */
+  int32_t k;              /* odd kernel size, padding k/2 (model.py:204) */
+  int32_t reserved0, reserved1;
+  const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */
+  const void* Wd;         /* dgrad weights (transposed + flipped), ET */
+  const float* bias_p;    /* bias permuted to gate-stash column order [4*Ch16] */
+} nint_layer;
+
+/* Everything one forward/backward over a (B,T) batch needs.  All pointers are device
+ * workspaces allocated by the caller; sizes follow from nint_seq_workspace_sizes(). */
+#define NINT_MAX_LAYERS 8
+typedef struct nint_seq {
+  int32_t dtype;            /* NINT_F32 | NINT_BF16: storage type ET of halo slabs / stash / weights */
+  int32_t B, T, L;
+  int32_t need_dx;          /* backward also produces d/dx of the input sequence */
+  int32_t has_init_state;   /* 0: h0=c0=0 (reference ConvLSTM, model.py:259-262); 1: h[l][0], c0[l] given */
+  int32_t n_cu;             /* CU count used to size split-K grids */
+  int32_t reserved;
+  nint_geom g;
+  nint_layer layer[NINT_MAX_LAYERS];
+  const void* xs;                      /* ET halo slab [T*B][Hh][Wh][Cxp0]: packed input sequence */
+  void* h[NINT_MAX_LAYERS];            /* ET halo slab [(T+1)*B][Hh][Wh][Chp]: h[0]=initial, h[t+1]=h_t */
+  float* c[NINT_MAX_LAYERS];           /* f32 compact [(T+1)*B][H][W][Chp]: c[0]=initial, c[t+1]=c_t */
+  void* gates[NINT_MAX_LAYERS];        /* ET stash [T*B][H][W][4*Ch16] post-activation i,f,g,o (training only; may be NULL) */
+  void* dG[NINT_MAX_LAYERS];           /* ET halo slab [T*B][Hh][Wh][4*Ch16] pre-activation gate grads */
+  float* dh[NINT_MAX_LAYERS];          /* f32 compact [B][H][W][Chp] running dL/dh_t (in: dL/dh_{T-1}, out: dL/dh_init) */
+  float* dc[NINT_MAX_LAYERS];          /* f32 compact [B][H][W][Chp] running dL/dc_t */
+  float* dx;                           /* f32 compact [T*B][H][W][Cxp0] (need_dx only) */
+  float* dW[NINT_MAX_LAYERS];          /* f32 OIHW (4Ch, Cx+Ch, k, k) gradient, overwritten */
+  float* db[NINT_MAX_LAYERS];          /* f32 (4Ch) gradient, overwritten */
+  float* wg_partial;                   /* f32 split-K slabs for wgrad (size from nint_seq_workspace_sizes) */
+  size_t wg_partial_bytes;
+} nint_seq;
+
+/* ---- library / device ---------------------------------------------------------------- */
+int nint_version(void);
+const char* nint_error_string(int code);
+/* host out-params */
+int nint_device_info(int* n_cu, int* lds_bytes_per_cu, int* wave_size, char* name, int name_len);
+/* Hardware self-test used by tests: MFMA fragment maps and ds_read_b64_tr_b16 semantics.
+ * out: device buffer of >= 4096 floats. */
+int nint_selftest(float* out, void* stream);
+
+/* channel padding rule: KC = 16 (f32) or 32 (bf16) channels = 64 bytes per pixel per K-step */
+int nint_kc(int dtype);
+int nint_geom_make(nint_geom* g /*host*/, int H, int W, int P);
+
+/* ---- layout conversion at the boundary ------------------------------------------------- */
+/* x (B,T,C,H,W) f32 contiguous (model.py:255) -> halo slab image t*B+b.  Replaces the
+ * `x[:, t]` slicing of model.py:266 and torch.cat of model.py:219 (never materialised). */
+int nint_pack_btchw(const float* src, void* dst, int B, int T, int C, int Cp, const nint_geom* g,
+                    int dtype, void* stream);
+/* halo slab images [n0, n0+N) -> (N,C,H,W) f32 */
+int nint_unpack_halo(const void* src, float* dst, int n0, int N, int C, int Cp, const nint_geom* g,
+                     int dtype, void* stream);
+/* (N,C,H,W) f32 <-> compact f32 slab [N][H][W][Cp] */
+int nint_pack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream);
+int nint_unpack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream);
+
+/* ---- weights ----------------------------------------------------------------------------- */
+/* bytes of the packed fwd / dgrad weight images of one layer */
+size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int dgrad);
+/* W (4Ch, Cx+Ch, k, k) f32 OIHW + bias (4Ch) as nn.Conv2d stores them (model.py:207-211)
+ * -> Wf, Wd (fragment order, ET) and bias_p.  Must be re-run after every optimiser step. */
+int nint_pack_weights(const float* W, const float* bias, void* Wf, void* Wd, float* bias_p,
+                      int Cx, int Ch, int k, int dtype, void* stream);
+
+/* ---- the hot path: one cell step ----------------------------------------------------------- */
+/* ConvLSTMCell.forward (model.py:216-231): gates = conv(cat[x,h]) ; sigmoid/tanh ; c,h update,
+ * fused.  x_slab/h_prev halo slabs (image n0x.. / n0h..), c_prev/c_out compact, h_out halo slab,
+ * gates_out stash (NULL in inference).  h_prev == NULL means h_prev = 0 (skips that half of K). */
+int nint_cell_fwd(const nint_layer* ly /*host*/, const nint_geom* g /*host*/, int dtype, int N,
+                  const void* x_slab, const void* h_prev, const float* c_prev,
+                  void* h_out, float* c_out, void* gates_out, void* stream);
+
+/* autograd backward of model.py:223-229 (pointwise part): consumes dh, dc (in place -> dc_prev),
+ * the stashed gates and c_prev / c_new; writes pre-activation gate grads into the dG halo slab. */
+int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N,
+                            const void* gates, const float* c_prev, const float* c_new,
+                            const float* dh, float* dc, void* dG, void* stream);
+
+/* conv backward-data of model.py:220: d cat[x,h] = W^T (*) dG.  h columns are STORED to dh_prev,
+ * x columns are ACCUMULATED (+=) into dx_accum (the layer below's dh, or dx); either may be NULL. */
+int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
+                    const void* dG, float* dx_accum, float* dh_prev, void* stream);
+
+/* conv backward-weight of model.py:220 over N = T*B images in ONE launch (all time steps):
+ * dW[o][c][ky][kx] = sum_n,y,x dG[n,y,x,o] * cat[n,y+ky-p,x+kx-p,c] ; db[o] = sum dG.
+ * partial: split-K workspace of nint_wgrad_workspace_bytes(). */
+size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, int n_cu);
+int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
+                    const void* dG, const void* x_slab, const void* h_slab,
+                    float* dW, float* db, float* partial, size_t partial_bytes, int n_cu, void* stream);
+
+/* ---- whole-sequence drivers (model.py:253-274 and its BPTT), all launches from C++ ---------- */
+int nint_seq_fwd(const nint_seq* s /*host*/, void* stream);
+int nint_seq_bwd(const nint_seq* s /*host*/, void* stream);
+
+/* ---- 1x1 head (model.py:251,274) ------------------------------------------------------------ */
+/* pred (N,O,H,W) f32 = w (O,Ch) . h + b  from halo-slab images [n0, n0+N) */
+int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w, const float* b,
+                  float* pred, const nint_geom* g, int dtype, void* stream);
+/* dh (compact f32 [N][H][W][Chp], overwritten) ; dw (O,Ch), db (O) overwritten */
+int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
+                  const float* dpred, float* dh, float* dw, float* db, const nint_geom* g, int dtype,
+                  void* stream);
+
+/* ---- loss (train.py:102,105) ------------------------------------------------------------------ */
+/* pred (N,O,H,W) f32, y (N,O,Hc,Wc) f32; crop window [oy,oy+Hc) x [ox,ox+Wc).
+ * loss_out: NINT_LOSS_SCRATCH_FLOATS floats, 8-byte aligned; [0] = mean((y-p)^2) + mean(|y-p|), the
+ * rest is reduction scratch; dpred (N,O,H,W) = d loss / d pred (0 outside the
+ * crop), may be NULL; stats (5 doubles, accumulated, caller zeroes): sum (y-p)^2, sum |y-p|,
+ * sum y, sum y^2, count -- the device-side R2 accumulators replacing train.py:113-114. */
+#define NINT_LOSS_SCRATCH_FLOATS 2050
+int nint_loss_mse_l1_crop(const float* pred, const float* y, float* dpred, float* loss_out, double* stats,
+                          int N, int O, int H, int W, int oy, int ox, int Hc, int Wc, void* stream);
+
+/* ---- optimiser (train.py:71,110) ---------------------------------------------------------------- */
+/* torch.optim.Adam (eps 1e-8, no weight decay / amsgrad) on one flat f32 buffer.
+ * grad_scale multiplies g first (1/world_size after the RCCL all-reduce). step is 1-based. */
+int nint_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* ---- preproc (dataset.py:520-536, 61-98) --------------------------------------------------------- */
+/* srcs: host array of nsrc device pointers, each (T, lev_i, H, W) f32 with lev[i] levels
+ * (u,v,omega at L levels, prec and emission at 1) -> out (T, C=sum lev, Hp, Wp) f32:
+ * fuse on the channel axis, z-score with mean/std (C floats, device), cyclic-lon + lat halo.
+ * mode 0 = the committed reference behaviour (np.fliplr on the channel axis, dataset.py:96),
+ * mode 1 = true latitude reflect (dataset.py:51 semantics). */
+int nint_preproc_fuse_pad(const float* const* srcs /*host*/, const int* lev /*host*/, int nsrc,
+                          const float* mean, const float* std, float* out, int T, int H, int W,
+                          int Hp, int Wp, int mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NINT_H */

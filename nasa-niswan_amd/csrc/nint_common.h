@@ -1,0 +1,112 @@
+// nint_common.h -- shared device/host helpers for the gfx950 ConvLSTM kernels.
+// Written for CDNA4 only: 64-wide waves, MFMA 16x16 tiles, 160 KiB LDS, no other targets.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nint.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#define NINT_CHECK_HIP(expr)                      \
+  do {                                            \
+    hipError_t _e = (expr);                       \
+    if (_e != hipSuccess) return (int)_e;         \
+  } while (0)
+
+#define NINT_LAUNCH_CHECK()                       \
+  do {                                            \
+    hipError_t _e = hipGetLastError();            \
+    if (_e != hipSuccess) return (int)_e;         \
+  } while (0)
+
+// Element-type traits. One K-step of the implicit GEMMs always covers 64 BYTES of channels
+// per pixel: 32 bf16 (one v_mfma_f32_16x16x32_bf16) or 16 f32 (four v_mfma_f32_16x16x4_f32).
+template <int DT> struct Elem;
+template <> struct Elem<NINT_F32> {
+  typedef float type;
+  static constexpr int ES = 4;    // bytes per element
+  static constexpr int KC = 16;   // channels per K-step
+  static constexpr int EPL = 4;   // elements per lane per K-step (16 bytes)
+};
+template <> struct Elem<NINT_BF16> {
+  typedef __bf16 type;
+  static constexpr int ES = 2;
+  static constexpr int KC = 32;
+  static constexpr int EPL = 8;
+};
+
+__host__ __device__ inline int nint_round_up(int a, int b) { return (a + b - 1) / b * b; }
+__host__ __device__ inline int nint_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// float -> bf16 round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+// and keeps NaN a NaN (MI355X_MICROARCH.md, correctness boundaries).
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float bf2f(uint16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+
+template <int DT> __device__ __forceinline__ float load_elem(const void* p, size_t i);
+template <> __device__ __forceinline__ float load_elem<NINT_F32>(const void* p, size_t i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float load_elem<NINT_BF16>(const void* p, size_t i) { return bf2f(((const uint16_t*)p)[i]); }
+template <int DT> __device__ __forceinline__ void store_elem(void* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_elem<NINT_F32>(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ __forceinline__ void store_elem<NINT_BF16>(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
+
+// One K-step of D += A*B on a 16x16 tile from two 16-byte fragments.
+//   bf16: lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], j=0..7
+//   f32 : four MFMAs; in MFMA j lane l supplies A[row l&15][k = l>>4] = element j of its fragment,
+//         i.e. channel 4*(l>>4)+j of the K-step -- the same bytes-per-lane geometry as bf16.
+template <int DT> __device__ __forceinline__ f32x4_t mma_step(u32x4_t a, u32x4_t b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t mma_step<NINT_BF16>(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mma_step<NINT_F32>(u32x4_t a, u32x4_t b, f32x4_t c) {
+  f32x4_t af = __builtin_bit_cast(f32x4_t, a), bf = __builtin_bit_cast(f32x4_t, b);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
+  return c;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh through exp; exact to ~1e-7 relative for the |x| range of LSTM pre-activations and
+// saturates cleanly for large |x| (exp overflow -> inf -> 1 - 0).
+__device__ __forceinline__ float tanhf_(float x) {
+  float e = __expf(-2.0f * fabsf(x));
+  float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, x);
+}
+
+// launcher-side descriptors -----------------------------------------------------------------
+struct ConvArgs {
+  const char* src0;      // halo slab (x for fwd, dG for dgrad)
+  const char* src1;      // second halo slab (h_prev) or nullptr
+  int nchunk0, nchunk1;  // 64-byte channel chunks taken from src0 / src1
+  long img_stride0, img_stride1;  // bytes per image
+  int pix_stride0, pix_stride1;   // bytes per pixel
+  const char* Bp;        // packed weights [S][NTt][64 lanes][16 B]
+  int NTt;               // n-tiles per K-step in Bp
+  int nt_begin;          // first n-tile this launch computes
+  int k, p, taps;
+  int H, W, P, Hh, Wh;
+  int tiles_x, tiles_y;
+  int cpf;               // channel chunks per LDS A fill
+  int a_bytes;           // bytes reserved for the A image
+  // LSTM epilogue
+  const float* bias;     // [4*Ch16] permuted
+  const float* c_prev;   // compact [N][H][W][Chp] or nullptr (= 0)
+  float* c_out;
+  char* h_out;           // halo slab, ET
+  char* gates_out;       // stash [N][H][W][4*Ch16] ET or nullptr
+  int Chp, Ch16;
+  // DGRAD epilogue
+  float* out0;           // += columns [0, C0p)
+  float* out1;           // =  columns [C0p, C0p+C1p)
+  int C0p, C1p;
+};

@@ -1,0 +1,555 @@
+// pointwise.hip -- the HBM-bound kernels around the gate GEMMs: layout conversion at the
+// boundary, weight packing into MFMA fragment order, the LSTM pointwise backward, the 1x1
+// head, the fused crop+MSE+L1 loss, flat Adam and the fuse/z-score/halo-pad preproc.
+// All of them are one-read/one-write streaming kernels; threads walk the channel axis
+// fastest so that channels-last slabs are read and written in full cache lines.
+#include "nint_common.h"
+
+static inline dim3 grid1d(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  if (g > 256 * 32) g = 256 * 32;   // grid-stride the rest (256 CUs x 32)
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+// ------------------------------------------------------------------------------ pack / unpack
+// (B,T,C,H,W) f32 -> halo slab image t*B+b, interior only (halo/slack stay zero).
+// Thread order: channel fastest on the WRITE side (full 64-byte rows); the NCHW read side is
+// strided by H*W floats per channel, served from L2 after the first touch of each line.
+template <int DT>
+__global__ void pack_btchw_kernel(const float* __restrict__ src, void* __restrict__ dst, int B, int T, int C,
+                                  int Cp, int H, int W, int P, int Hh, int Wh) {
+  const size_t total = (size_t)B * T * H * W * Cp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % Cp;
+    size_t r = i / Cp;
+    const int x = r % W; r /= W;
+    const int y = r % H; r /= H;
+    const int b = r % B;
+    const int t = r / B;
+    const float v = c < C ? src[((((size_t)b * T + t) * C + c) * H + y) * W + x] : 0.f;
+    const size_t o = ((((size_t)t * B + b) * Hh + (y + P)) * Wh + (x + P)) * Cp + c;
+    store_elem<DT>(dst, o, v);
+  }
+}
+
+template <int DT>
+__global__ void unpack_halo_kernel(const void* __restrict__ src, float* __restrict__ dst, int n0, int N, int C,
+                                   int Cp, int H, int W, int P, int Hh, int Wh) {
+  const size_t total = (size_t)N * C * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    size_t r = i / W;
+    const int y = r % H; r /= H;
+    const int c = r % C;
+    const int n = r / C;
+    const size_t s = ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Cp + c;
+    dst[i] = load_elem<DT>(src, s);
+  }
+}
+
+__global__ void pack_compact_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int Cp,
+                                    int H, int W) {
+  const size_t total = (size_t)N * H * W * Cp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % Cp;
+    size_t r = i / Cp;
+    const int x = r % W; r /= W;
+    const int y = r % H;
+    const int n = r / H;
+    dst[i] = c < C ? src[(((size_t)n * C + c) * H + y) * W + x] : 0.f;
+  }
+}
+
+__global__ void unpack_compact_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int Cp,
+                                      int H, int W) {
+  const size_t total = (size_t)N * C * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    size_t r = i / W;
+    const int y = r % H; r /= H;
+    const int c = r % C;
+    const int n = r / C;
+    dst[i] = src[(((size_t)n * H + y) * W + x) * Cp + c];
+  }
+}
+
+extern "C" int nint_pack_btchw(const float* src, void* dst, int B, int T, int C, int Cp, const nint_geom* g,
+                               int dtype, void* stream) {
+  if (!src || !dst || !g || B <= 0 || T <= 0 || C <= 0 || Cp < C) return NINT_E_ARG;
+  const size_t total = (size_t)B * T * g->H * g->W * Cp;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(pack_btchw_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+  else if (dtype == NINT_F32)
+    hipLaunchKernelGGL(pack_btchw_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+  else
+    return NINT_E_ARG;
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+extern "C" int nint_unpack_halo(const void* src, float* dst, int n0, int N, int C, int Cp, const nint_geom* g,
+                                int dtype, void* stream) {
+  if (!src || !dst || !g || N <= 0 || C <= 0 || Cp < C || n0 < 0) return NINT_E_ARG;
+  const size_t total = (size_t)N * C * g->H * g->W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(unpack_halo_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, src, dst, n0, N, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+  else if (dtype == NINT_F32)
+    hipLaunchKernelGGL(unpack_halo_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, src, dst, n0, N, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+  else
+    return NINT_E_ARG;
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+extern "C" int nint_pack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || Cp < C) return NINT_E_ARG;
+  hipLaunchKernelGGL(pack_compact_kernel, grid1d((size_t)N * H * W * Cp), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+extern "C" int nint_unpack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || Cp < C) return NINT_E_ARG;
+  hipLaunchKernelGGL(unpack_compact_kernel, grid1d((size_t)N * C * H * W), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ weight packing
+// Fragment order: Bp[s][nt][lane][e]; s = chunk*taps + tap; lane = 16*g + col;
+// the lane's e-th element is K-channel chunk*KC + g*EPL + e and output column nt*16 + col.
+//   fwd  : K-channel -> cat[x,h] channel (x part padded to Cxp), column n' -> gate*Ch + cblock*16+col
+//   dgrad: K-channel -> gate column n' of dG, column -> cat channel, taps flipped
+template <int DT>
+__global__ void pack_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias, void* __restrict__ Wf,
+                                    void* __restrict__ Wd, float* __restrict__ bias_p, int Cx, int Cxp, int Ch, int Ch16,
+                                    int Chp, int k) {
+  typedef Elem<DT> E;
+  const int taps = k * k;
+  const int Ctot = Cx + Ch;
+  const int ntf = 4 * Ch16 / 16;
+  const int sf = (Cxp + Chp) / E::KC * taps;
+  const size_t nf = (size_t)sf * ntf * 64 * E::EPL;
+  const int ntd = (Cxp + Chp) / 16;
+  const int sd = 4 * Ch16 / E::KC * taps;
+  const size_t nd = (size_t)sd * ntd * 64 * E::EPL;
+  const size_t nb = 4 * Ch16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nf + nd + nb; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int e = i % E::EPL;
+      size_t r = i / E::EPL;
+      const int lane = r % 64; r /= 64;
+      const int nt = r % ntf;
+      const int s = r / ntf;
+      const int chunk = s / taps, tap = s % taps;
+      const int kc = chunk * E::KC + (lane >> 4) * E::EPL + e;       // channel in padded cat space
+      int ic = -1;
+      if (kc < Cxp) { if (kc < Cx) ic = kc; }
+      else { const int hc = kc - Cxp; if (hc < Ch) ic = Cx + hc; }
+      const int cblock = nt / 4, gate = nt % 4, col = lane & 15;
+      const int ch = cblock * 16 + col;
+      float v = 0.f;
+      if (ic >= 0 && ch < Ch) v = W[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap];
+      store_elem<DT>(Wf, i, v);
+    } else if (i < nf + nd) {
+      const size_t ii = i - nf;
+      const int e = ii % E::EPL;
+      size_t r = ii / E::EPL;
+      const int lane = r % 64; r /= 64;
+      const int nt = r % ntd;
+      const int s = r / ntd;
+      const int chunk = s / taps, tap = s % taps;
+      const int np = chunk * E::KC + (lane >> 4) * E::EPL + e;       // gate column n' of dG
+      const int cblock = np / 64, gate = (np % 64) / 16, colk = np % 16;
+      const int ch = cblock * 16 + colk;
+      const int j = nt * 16 + (lane & 15);                           // cat channel (padded space)
+      int ic = -1;
+      if (j < Cxp) { if (j < Cx) ic = j; }
+      else { const int hc = j - Cxp; if (hc < Ch) ic = Cx + hc; }
+      const int ty = tap / k, tx = tap % k;
+      const int ftap = (k - 1 - ty) * k + (k - 1 - tx);
+      float v = 0.f;
+      if (ic >= 0 && ch < Ch) v = W[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + ftap];
+      store_elem<DT>(Wd, ii, v);
+    } else {
+      const int n = (int)(i - nf - nd);
+      const int cblock = n / 64, gate = (n % 64) / 16, col = n % 16;
+      const int ch = cblock * 16 + col;
+      bias_p[n] = (ch < Ch && bias) ? bias[gate * Ch + ch] : 0.f;
+    }
+  }
+}
+
+extern "C" int nint_kc(int dtype) { return dtype == NINT_BF16 ? 32 : (dtype == NINT_F32 ? 16 : NINT_E_ARG); }
+
+extern "C" size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int dgrad) {
+  const int kc = nint_kc(dtype);
+  if (kc < 0) return 0;
+  const int es = dtype == NINT_BF16 ? 2 : 4;
+  const int Cxp = nint_round_up(Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
+  // both images hold (Cxp+Chp) x 4*Ch16 x taps elements
+  (void)dgrad;
+  return (size_t)(Cxp + Chp) * 4 * Ch16 * k * k * es;
+}
+
+extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, void* Wd, float* bias_p, int Cx,
+                                 int Ch, int k, int dtype, void* stream) {
+  if (!W || !Wf || !Wd || !bias_p || Cx <= 0 || Ch <= 0 || !(k & 1)) return NINT_E_ARG;
+  const int kc = nint_kc(dtype);
+  if (kc < 0) return NINT_E_ARG;
+  const int Cxp = nint_round_up(Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
+  const size_t n = 2 * (size_t)(Cxp + Chp) * 4 * Ch16 * k * k + 4 * Ch16;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<NINT_BF16>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<NINT_F32>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ LSTM pointwise backward
+// Per (pixel, hidden channel), SURVEY.md section 8 a-5 / autograd of model.py:223-229:
+//   tc = tanh(c'), do = dh*tc, dc += dh*o*(1-tc^2), di = dc*g, df = dc*c, dg = dc*i, dc_prev = dc*f
+//   dGi = di*i*(1-i), dGf = df*f*(1-f), dGg = dg*(1-g^2), dGo = do*o*(1-o)
+// Reads the gate stash (ET), c_prev / c_new / dh / dc (f32); writes dG into its halo slab (ET,
+// interior only) and dc_prev in place.  One thread per (pixel, channel), channel fastest.
+template <int DT>
+__global__ void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
+                                          const float* __restrict__ c_new, const float* __restrict__ dh,
+                                          float* __restrict__ dc, void* __restrict__ dG, int N, int H, int W, int P,
+                                          int Hh, int Wh, int Ch16, int Chp) {
+  const size_t total = (size_t)N * H * W * Ch16;
+  const int Gc = 4 * Ch16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = i % Ch16;
+    const size_t pix = i / Ch16;
+    const int x = pix % W;
+    size_t r = pix / W;
+    const int y = r % H;
+    const int n = r / H;
+    const int cblock = ch >> 4, col = ch & 15;
+    const size_t gb = pix * Gc + (size_t)cblock * 64 + col;
+    const float gi = load_elem<DT>(gates, gb);
+    const float gf = load_elem<DT>(gates, gb + 16);
+    const float gg = load_elem<DT>(gates, gb + 32);
+    const float go = load_elem<DT>(gates, gb + 48);
+    const size_t ci = pix * Chp + ch;
+    const float cp = c_prev ? c_prev[ci] : 0.f;
+    const float tc = tanhf_(c_new[ci]);
+    const float dhv = dh[ci];
+    const float dct = dc[ci] + dhv * go * (1.f - tc * tc);
+    const float d_o = dhv * tc;
+    const size_t ob = ((((size_t)n * Hh) + (y + P)) * Wh + (x + P)) * Gc + (size_t)cblock * 64 + col;
+    store_elem<DT>(dG, ob, dct * gg * gi * (1.f - gi));
+    store_elem<DT>(dG, ob + 16, dct * cp * gf * (1.f - gf));
+    store_elem<DT>(dG, ob + 32, dct * gi * (1.f - gg * gg));
+    store_elem<DT>(dG, ob + 48, d_o * go * (1.f - go));
+    dc[ci] = dct * gf;
+  }
+}
+
+extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
+                                       const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
+                                       void* stream) {
+  if (!ly || !g || !gates || !c_new || !dh || !dc || !dG || N <= 0) return NINT_E_ARG;
+  const size_t total = (size_t)N * g->H * g->W * ly->Ch16;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp);
+  else if (dtype == NINT_F32)
+    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp);
+  else
+    return NINT_E_ARG;
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ 1x1 head
+// pred[n][o][y][x] = b[o] + sum_c w[o][c] * h[n][y][x][c]     (model.py:251,274)
+template <int DT>
+__global__ void head_fwd_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp, int O,
+                                const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ pred,
+                                int H, int W, int P, int Hh, int Wh) {
+  const size_t total = (size_t)N * O * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    size_t r = i / W;
+    const int y = r % H; r /= H;
+    const int o = r % O;
+    const int n = r / O;
+    const size_t hb = ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp;
+    float acc = b ? b[o] : 0.f;
+    for (int c = 0; c < Ch; ++c) acc += w[o * Ch + c] * load_elem<DT>(h, hb + c);
+    pred[i] = acc;
+  }
+}
+
+// dh[n][y][x][c] = sum_o w[o][c] * dpred[n][o][y][x]; one thread per (pixel, padded channel)
+__global__ void head_bwd_dh_kernel(const float* __restrict__ w, const float* __restrict__ dpred, float* __restrict__ dh,
+                                   int N, int Ch, int Chp, int O, int H, int W) {
+  const size_t total = (size_t)N * H * W * Chp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % Chp;
+    const size_t pix = i / Chp;
+    const size_t yx = pix % ((size_t)H * W);
+    const int n = pix / ((size_t)H * W);
+    float acc = 0.f;
+    if (c < Ch)
+      for (int o = 0; o < O; ++o) acc += w[o * Ch + c] * dpred[((size_t)n * O + o) * H * W + yx];
+    dh[i] = acc;
+  }
+}
+
+// dw[o][c] = sum_pixels dpred*h ; db[o] = sum dpred.  One workgroup per (o, c-or-bias) output,
+// fixed-order tree reduction -> bitwise reproducible.
+template <int DT>
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp,
+                                                          int O, const float* __restrict__ dpred,
+                                                          float* __restrict__ dw, float* __restrict__ db, int H, int W,
+                                                          int P, int Hh, int Wh) {
+  const int o = blockIdx.x / (Ch + 1);
+  const int c = blockIdx.x % (Ch + 1);   // c == Ch -> bias
+  const size_t npix = (size_t)N * H * W;
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < npix; i += blockDim.x) {
+    const int x = i % W;
+    size_t r = i / W;
+    const int y = r % H;
+    const int n = r / H;
+    const float d = dpred[(((size_t)n * O + o) * H + y) * W + x];
+    if (c < Ch) {
+      const size_t hb = ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp + c;
+      acc += d * load_elem<DT>(h, hb);
+    } else {
+      acc += d;
+    }
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (c < Ch) dw[o * Ch + c] = red[0];
+    else db[o] = red[0];
+  }
+}
+
+extern "C" int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
+                             const float* b, float* pred, const nint_geom* g, int dtype, void* stream) {
+  if (!h_slab || !w || !pred || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
+  const size_t total = (size_t)N * O * g->H * g->W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(head_fwd_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+  else if (dtype == NINT_F32)
+    hipLaunchKernelGGL(head_fwd_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+  else
+    return NINT_E_ARG;
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
+                             const float* dpred, float* dh, float* dw, float* db, const nint_geom* g, int dtype,
+                             void* stream) {
+  if (!h_slab || !w || !dpred || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dh) {
+    hipLaunchKernelGGL(head_bwd_dh_kernel, grid1d((size_t)N * g->H * g->W * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    NINT_LAUNCH_CHECK();
+  }
+  if (dw && db) {
+    if (dtype == NINT_BF16)
+      hipLaunchKernelGGL(head_bwd_dw_kernel<NINT_BF16>, dim3(O * (Ch + 1)), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, dw, db, g->H, g->W, g->P, g->Hh, g->Wh);
+    else if (dtype == NINT_F32)
+      hipLaunchKernelGGL(head_bwd_dw_kernel<NINT_F32>, dim3(O * (Ch + 1)), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, dw, db, g->H, g->W, g->P, g->Hh, g->Wh);
+    else
+      return NINT_E_ARG;
+    NINT_LAUNCH_CHECK();
+  }
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ loss
+// train.py:102,105: crop, MSELoss + L1Loss (mean).  Two launches on the same stream:
+//  (1) per-block partial sums in double (fixed order), (2) one block folds them, writes
+//  the loss and adds to the 5 running statistics.  dpred = (2(p-y) + sign(p-y)) / n on the crop.
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                           float* __restrict__ dpred, double* __restrict__ partial,
+                                                           int N, int O, int H, int W, int oy, int ox, int Hc, int Wc) {
+  const size_t total = (size_t)N * O * H * W;
+  const double inv_n = 1.0 / ((double)N * O * Hc * Wc);
+  double s2 = 0, s1 = 0, sy = 0, syy = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    size_t r = i / W;
+    const int yy = r % H;
+    const size_t no = r / H;
+    const int cy = yy - oy, cx = x - ox;
+    float g = 0.f;
+    if (cy >= 0 && cy < Hc && cx >= 0 && cx < Wc) {
+      const float t = y[(no * Hc + cy) * Wc + cx];
+      const float d = pred[i] - t;
+      s2 += (double)d * d;
+      s1 += fabs((double)d);
+      sy += t;
+      syy += (double)t * t;
+      g = (float)((2.0 * d + (d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0))) * inv_n);
+    }
+    if (dpred) dpred[i] = g;
+  }
+  __shared__ double red[4][256];
+  red[0][threadIdx.x] = s2; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = sy; red[3][threadIdx.x] = syy;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void loss_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ loss_out,
+                                  double* __restrict__ stats, double count) {
+  if (threadIdx.x == 0) {
+    double s[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+      for (int q = 0; q < 4; ++q) s[q] += partial[b * 4 + q];
+    if (loss_out) loss_out[0] = (float)(s[0] / count + s[1] / count);
+    if (stats) {
+      stats[0] += s[0]; stats[1] += s[1]; stats[2] += s[2]; stats[3] += s[3]; stats[4] += count;
+    }
+  }
+}
+
+// partial sums live in a small static device buffer per call site: the caller passes it as the
+// tail of `stats` would complicate the ABI, so the kernel pair uses dpred-independent scratch
+// carved from loss_out[1..]: loss_out must have room for 1 + 2*LOSS_BLOCKS*4 floats.
+#define LOSS_BLOCKS 256
+extern "C" int nint_loss_mse_l1_crop(const float* pred, const float* y, float* dpred, float* loss_out, double* stats,
+                                     int N, int O, int H, int W, int oy, int ox, int Hc, int Wc, void* stream) {
+  if (!pred || !y || !loss_out || N <= 0 || O <= 0 || oy < 0 || ox < 0 || oy + Hc > H || ox + Wc > W) return NINT_E_ARG;
+  if ((((uintptr_t)loss_out) & 7) != 0) return NINT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)(loss_out + 2);   // loss_out: [0]=loss, [1]=pad, [2..] = 256*4 doubles
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, pred, y, dpred, partial, N, O, H, W, oy, ox, Hc, Wc);
+  NINT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, partial, LOSS_BLOCKS, loss_out, stats, (double)N * O * Hc * Wc);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ Adam
+// torch.optim.Adam single-tensor update order (train.py:71,110):
+//   m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, size_t n, float step_size, float b1, float b2, float eps,
+                                 float inv_sqrt_bc2_denom, float grad_scale) {
+  const float w1 = 1.f - b1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gr = g[i] * grad_scale;
+    float mi = m[i], vi = v[i];
+    // torch lerp: a + w*(b-a) for w < 0.5, else b - (b-a)*(1-w)
+    mi = (w1 < 0.5f) ? __fadd_rn(mi, __fmul_rn(w1, __fsub_rn(gr, mi)))
+                     : __fsub_rn(gr, __fmul_rn(__fsub_rn(gr, mi), 1.f - w1));
+    vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(1.f - b2, gr), gr));   // addcmul: (value*t1)*t2
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), inv_sqrt_bc2_denom), eps);
+    p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(-step_size, mi), denom));          // addcdiv: (value*t1)/t2
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+extern "C" int nint_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                              float beta2, float eps, int step, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || step < 1) return NINT_E_ARG;
+  if (n == 0) return NINT_OK;
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float sqrt_bc2 = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_flat_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1, beta2, eps, sqrt_bc2, grad_scale);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ preproc
+// dataset.py:526-536 through :67-98.  Output element (t, c, yp, xp):
+//   lon: cyclic, xs = (xp - pl) mod W                            (dataset.py:67-80)
+//   lat: top halo row j (< pt)  <- source row 1+j      (mode 0, channel C-1-c: np.fliplr quirk, dataset.py:96)
+//                                <- source row pt-j     (mode 1, true reflect, dataset.py:51 semantics)
+//        bottom halo row j      <- source row H-pb-1+j  (mode 0, channel C-1-c) / H-2-j (mode 1)
+//   value = (src - mean[c]) / std[c]                              (dataset.py:528), with mean/std of
+//   the SOURCE channel that is actually read (the reference z-scores before it pads).
+#define PRE_MAX_SRC 16
+struct PreArgs {
+  const float* src[PRE_MAX_SRC];
+  int first_c[PRE_MAX_SRC + 1];   // first fused channel of each source
+  int nsrc;
+};
+
+__global__ void preproc_kernel(PreArgs a, const float* __restrict__ mean, const float* __restrict__ stdv,
+                               float* __restrict__ out, int T, int C, int H, int W, int Hp, int Wp, int mode) {
+  const int pl = (Wp - W) / 2;
+  const int pt = (Hp - H) / 2;
+  const int pb = Hp - H - pt;
+  const size_t total = (size_t)T * C * Hp * Wp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xp = i % Wp;
+    size_t r = i / Wp;
+    const int yp = r % Hp; r /= Hp;
+    int c = r % C;
+    const int t = r / C;
+    int xs = xp - pl;
+    if (xs < 0) xs += W;
+    else if (xs >= W) xs -= W;
+    int ys;
+    if (yp < pt) {
+      if (mode == 0) { ys = 1 + yp; c = C - 1 - c; }
+      else ys = pt - yp;
+    } else if (yp < pt + H) {
+      ys = yp - pt;
+    } else {
+      const int j = yp - pt - H;
+      if (mode == 0) { ys = H - pb - 1 + j; c = C - 1 - c; }
+      else ys = H - 2 - j;
+    }
+    int s = 0;
+    while (s + 1 < a.nsrc && c >= a.first_c[s + 1]) ++s;
+    const int lev = c - a.first_c[s];
+    const int nlev = a.first_c[s + 1] - a.first_c[s];
+    const float v = a.src[s][(((size_t)t * nlev + lev) * H + ys) * W + xs];
+    out[i] = (v - mean[c]) / stdv[c];
+  }
+}
+
+extern "C" int nint_preproc_fuse_pad(const float* const* srcs, const int* lev, int nsrc, const float* mean,
+                                     const float* stdv, float* out, int T, int H, int W, int Hp, int Wp, int mode,
+                                     void* stream) {
+  if (!srcs || !lev || nsrc <= 0 || nsrc > PRE_MAX_SRC || !mean || !stdv || !out || T <= 0) return NINT_E_ARG;
+  if (Hp < H || Wp < W || (mode != 0 && mode != 1)) return NINT_E_ARG;
+  const int pl = (Wp - W) / 2, pr = Wp - W - pl, pt = (Hp - H) / 2, pb = Hp - H - pt;
+  // the reference raises AttributeError for oversize padding (dataset.py:80,98)
+  if (pl > W || pr > W || pt + 1 > H || pb + 1 > H) return NINT_E_SHAPE;
+  PreArgs a;
+  a.nsrc = nsrc;
+  int c = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (!srcs[i] || lev[i] <= 0) return NINT_E_ARG;
+    a.src[i] = srcs[i];
+    a.first_c[i] = c;
+    c += lev[i];
+  }
+  a.first_c[nsrc] = c;
+  const size_t total = (size_t)T * c * Hp * Wp;
+  hipLaunchKernelGGL(preproc_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, a, mean, stdv, out, T, c, H, W, Hp, Wp, mode);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}

@@ -1,0 +1,174 @@
+// seq.hip -- library entry points that are not kernels themselves: version / device info,
+// the hardware self-test, and the whole-sequence drivers that enqueue every launch of a
+// ConvLSTM forward (model.py:253-274) or its BPTT from C++ on one HIP stream, so the Python
+// side pays one ctypes call per pass instead of one per kernel.
+#include <string.h>
+#include "nint_common.h"
+
+extern "C" int nint_version(void) { return NINT_VERSION; }
+
+extern "C" const char* nint_error_string(int code) {
+  switch (code) {
+    case NINT_OK: return "ok";
+    case NINT_E_ARG: return "nint: invalid argument";
+    case NINT_E_SHAPE: return "nint: shape not supported by any kernel instantiation";
+    case NINT_E_LDS: return "nint: tile does not fit in LDS";
+    case NINT_E_ALIGN: return "nint: pointer not 16-byte aligned";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "nint: unknown error";
+  }
+}
+
+extern "C" int nint_device_info(int* n_cu, int* lds_bytes_per_cu, int* wave_size, char* name, int name_len) {
+  int dev = 0;
+  NINT_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  NINT_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (wave_size) *wave_size = prop.warpSize;
+  if (name && name_len > 0) {
+    strncpy(name, prop.gcnArchName, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return NINT_OK;
+}
+
+extern "C" int nint_geom_make(nint_geom* g, int H, int W, int P) {
+  if (!g || H <= 0 || W <= 0 || P < 0) return NINT_E_ARG;
+  g->H = H; g->W = W; g->P = P;
+  g->Hh = nint_round_up(H, 8) + 2 * P;
+  g->Wh = nint_round_up(W, 32) + 2 * P;
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ self-test
+// out[0..255]     : D of mfma_f32_16x16x32_bf16 with A[m][k] = m + 1 (k == 3 only), B[k][n] = 32 + n (k == 3 only),
+//                   i.e. D[m][n] = (m+1)*(32+n) (asymmetric),
+//                   stored as out[lane*4 + r]   -> pins the C/D register map and the A/B k-slot pairing
+// out[1024..2047] : same for mfma_f32_16x16x4f32 with the one-hot k = 2
+// out[2048..2303] : ds_read_b64_tr_b16 of an LDS image img[row][col] = 64*row + col (16 columns,
+//                   32-byte rows), lane 4q+p of each 16-lane group addressing row 4*g+q, cols 4p..4p+3
+//                   stored as out[2048 + lane*4 + e]
+__global__ void selftest_kernel(float* out) {
+  const int lane = threadIdx.x;
+  const int g = lane >> 4, i16 = lane & 15;
+  {
+    bf16x8_t a, b;
+    for (int j = 0; j < 8; ++j) {
+      const int kk = 8 * g + j;
+      a[j] = (__bf16)(kk == 3 ? (float)(i16 + 1) : 0.f);
+      b[j] = (__bf16)(kk == 3 ? (float)(32 + i16) : 0.f);
+    }
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = c[r];
+  }
+  {
+    const float a = (g == 2) ? (float)(i16 + 1) : 0.f;
+    const float b = (g == 2) ? (float)(32 + i16) : 0.f;
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) out[1024 + lane * 4 + r] = c[r];
+  }
+  {
+    __shared__ __attribute__((aligned(16))) uint16_t img[16 * 16];
+    for (int i = lane; i < 256; i += 64) img[i] = (uint16_t)(64 * (i / 16) + (i % 16));
+    __syncthreads();
+    const int q = i16 >> 2, p = i16 & 3;
+    const char* ad = (const char*)img + (4 * g + q) * 32 + p * 8;
+    s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)ad);
+    for (int e = 0; e < 4; ++e) out[2048 + lane * 4 + e] = (float)(uint16_t)v[e];
+  }
+}
+
+extern "C" int nint_selftest(float* out, void* stream) {
+  if (!out) return NINT_E_ARG;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ sequence drivers
+static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
+
+static int seq_check(const nint_seq* s) {
+  if (!s || s->L < 1 || s->L > NINT_MAX_LAYERS || s->B < 1 || s->T < 1) return NINT_E_ARG;
+  if (s->dtype != NINT_F32 && s->dtype != NINT_BF16) return NINT_E_ARG;
+  if (!s->xs) return NINT_E_ARG;
+  for (int l = 0; l < s->L; ++l) {
+    if (!s->h[l] || !s->c[l]) return NINT_E_ARG;
+    if (l > 0 && s->layer[l].Cxp != s->layer[l - 1].Chp) return NINT_E_ARG;
+  }
+  return NINT_OK;
+}
+
+extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
+  int rc = seq_check(s);
+  if (rc != NINT_OK) return rc;
+  const nint_geom* g = &s->g;
+  const size_t es = esize(s->dtype);
+  const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
+  const int B = s->B;
+  for (int t = 0; t < s->T; ++t) {                               // model.py:265
+    for (int l = 0; l < s->L; ++l) {                             // model.py:267
+      const nint_layer* ly = &s->layer[l];
+      const char* x_slab = (l == 0)
+          ? (const char*)s->xs + (size_t)t * B * halo_px * ly->Cxp * es            // x[:, t]  (model.py:266)
+          : (const char*)s->h[l - 1] + (size_t)(t + 1) * B * halo_px * ly->Cxp * es;  // h of the layer below (model.py:271)
+      const size_t hs = (size_t)B * halo_px * ly->Chp * es;
+      const size_t cs = (size_t)B * comp_px * ly->Chp;
+      const bool zero_state = (t == 0 && !s->has_init_state);     // model.py:259-262: zeros -> skip the h half of K
+      const char* h_prev = zero_state ? nullptr : (const char*)s->h[l] + (size_t)t * hs;
+      const float* c_prev = zero_state ? nullptr : s->c[l] + (size_t)t * cs;
+      char* h_out = (char*)s->h[l] + (size_t)(t + 1) * hs;
+      float* c_out = s->c[l] + (size_t)(t + 1) * cs;
+      char* gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
+      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
+      if (rc != NINT_OK) return rc;
+    }
+  }
+  return NINT_OK;
+}
+
+extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
+  int rc = seq_check(s);
+  if (rc != NINT_OK) return rc;
+  const nint_geom* g = &s->g;
+  const size_t es = esize(s->dtype);
+  const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
+  const int B = s->B;
+  for (int l = 0; l < s->L; ++l)
+    if (!s->gates[l] || !s->dG[l] || !s->dh[l] || !s->dc[l] || !s->dW[l] || !s->db[l]) return NINT_E_ARG;
+  if (s->need_dx && !s->dx) return NINT_E_ARG;
+  if (!s->wg_partial) return NINT_E_ARG;
+
+  for (int t = s->T - 1; t >= 0; --t) {
+    for (int l = s->L - 1; l >= 0; --l) {
+      const nint_layer* ly = &s->layer[l];
+      const size_t cs = (size_t)B * comp_px * ly->Chp;
+      const size_t Gc = 4 * (size_t)ly->Ch16;
+      const char* gates = (const char*)s->gates[l] + (size_t)t * B * comp_px * Gc * es;
+      char* dG = (char*)s->dG[l] + (size_t)t * B * halo_px * Gc * es;
+      // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
+      rc = nint_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
+                                   s->dh[l], s->dc[l], dG, stream);
+      if (rc != NINT_OK) return rc;
+      float* dx_accum = (l > 0) ? s->dh[l - 1]
+                                : (s->need_dx ? s->dx + (size_t)t * B * comp_px * ly->Cxp : nullptr);
+      // at t == 0 with a zero initial state nobody consumes d/dh_{-1}
+      float* dh_prev = (t == 0 && !s->has_init_state) ? nullptr : s->dh[l];
+      rc = nint_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, stream);
+      if (rc != NINT_OK) return rc;
+    }
+  }
+  // weight / bias gradients: one reduction over all T*B images per layer
+  for (int l = 0; l < s->L; ++l) {
+    const nint_layer* ly = &s->layer[l];
+    const char* x_all = (l == 0) ? (const char*)s->xs
+                                 : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
+    rc = nint_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
+                         s->wg_partial, s->wg_partial_bytes, s->n_cu, stream);
+    if (rc != NINT_OK) return rc;
+  }
+  return NINT_OK;
+}

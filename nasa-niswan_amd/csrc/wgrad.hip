@@ -1,0 +1,398 @@
+// wgrad.hip -- conv backward-weight for the ConvLSTM gate convolution on gfx950 MFMA.
+//
+//   dW[o][c][ky][kx] = sum_{n,y,x} dG[n,y,x,o] * cat[n, y+ky-p, x+kx-p, c]      (autograd of model.py:220)
+//
+// All T time steps are reduced in ONE launch per source (x / h): the BPTT loop only stores
+// dG_t, so the reduction dimension is K = T*B*H*W pixels and the grid is (split-K, output block).
+// GEMM view: M = 64 gate columns n' (4 MFMA row tiles), N = 16*NTC cat channels x all k*k taps,
+// K = pixels.  The MFMA K index runs over pixels, but the slabs are channels-last, so both
+// operands are read TRANSPOSED from their LDS images:
+//   bf16: ds_read_b64_tr_b16 -- a 16-lane group turns a 4-pixel x 16-channel block into
+//         "lane = channel, 4 pixels per lane"; two reads give the 8 K-slots of a 16x16x32 MFMA.
+//         A (dG) and B (cat, shifted by the tap) use the SAME pixel->K-slot assignment, which is
+//         all a reduction needs.
+//   f32 : plain ds_read_b32 (lane = channel) feeding v_mfma_f32_16x16x4_f32.
+// Taps are free: the cat image is a halo tile and a tap is a constant LDS address offset.
+// Each workgroup keeps its 64 x (16*NTC*taps) output block in accumulators for its whole pixel
+// range and writes ONE partial slab; a second kernel folds the slabs in fixed order
+// (bitwise reproducible, no float atomics) into the OIHW gradient.
+#include "nint_common.h"
+
+struct WgradArgs {
+  const char* dG; long dG_img_stride; int dG_pix_stride;
+  const char* src; long src_img_stride; int src_pix_stride;
+  float* partial;
+  int CB, NTC, J;
+  int k, p, taps;
+  int P, Wh;
+  int tiles_x, tiles_y, ntiles, tiles_per_split;
+};
+
+template <int DT> struct WgTile;
+template <> struct WgTile<NINT_BF16> { static constexpr int PR = 4, RA = 160; static constexpr int rb(int ntc) { return ntc == 1 ? 32 : 96; } };
+template <> struct WgTile<NINT_F32> { static constexpr int PR = 2, RA = 320; static constexpr int rb(int ntc) { return ntc == 1 ? 64 : 192; } };
+
+template <int DT, int JW>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+  typedef Elem<DT> E;
+  typedef WgTile<DT> TT;
+  constexpr int PR = TT::PR, RA = TT::RA;
+  constexpr int NTN = 4;
+  constexpr int A_UNITS_PIX = 64 * E::ES / 16;           // 16-byte units per dG pixel row (64 gate columns)
+  constexpr int A_UNITS = PR * 32 * A_UNITS_PIX;
+  constexpr int A_PER_THR = A_UNITS / 256;
+  static_assert(A_UNITS % 256 == 0, "dG tile must split evenly over the workgroup");
+  constexpr int B_PER_THR_MAX = 5;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = a.p, k = a.k;
+  const int HWt = 32 + 2 * p, HHt = PR + 2 * p;
+  const int RB = TT::rb(a.NTC);
+  const int b_units_pix = 16 * a.NTC * E::ES / 16;       // units per cat halo pixel
+  const int b_units = HHt * HWt * b_units_pix;
+  const int a_bytes = PR * 32 * RA;
+  const int b_bytes = nint_round_up(HHt * HWt * RB, 16);
+  const int buf_bytes = a_bytes + b_bytes;
+
+  const int nb = blockIdx.y / a.CB, cb = blockIdx.y % a.CB;
+  const int t_begin = blockIdx.x * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const int j0 = wave * JW;
+
+  f32x4_t acc[NTN][JW];
+#pragma unroll
+  for (int i = 0; i < NTN; ++i)
+#pragma unroll
+    for (int j = 0; j < JW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t areg[A_PER_THR], breg[B_PER_THR_MAX];
+
+  auto issue_loads = [&](int tile) {
+    const int tx = tile % a.tiles_x;
+    const int r = tile / a.tiles_x;
+    const int ty = r % a.tiles_y;
+    const int img = r / a.tiles_y;
+    const int y0 = ty * PR, x0 = tx * 32;
+    const char* ga = a.dG + (long)img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride +
+                     nb * 64 * E::ES;
+#pragma unroll
+    for (int i = 0; i < A_PER_THR; ++i) {
+      const int u = tid + i * 256;
+      const int q = u % A_UNITS_PIX, pix = u / A_UNITS_PIX;
+      const int py = pix >> 5, px = pix & 31;
+      areg[i] = *(const u32x4_t*)(ga + ((long)py * a.Wh + px) * a.dG_pix_stride + q * 16);
+    }
+    const char* gb = a.src + (long)img * a.src_img_stride +
+                     ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride + cb * 16 * a.NTC * E::ES;
+#pragma unroll
+    for (int i = 0; i < B_PER_THR_MAX; ++i) {
+      const int u = tid + i * 256;
+      if (u < b_units) {
+        const int q = u % b_units_pix, hp = u / b_units_pix;
+        const int hy = hp / HWt, hx = hp - hy * HWt;
+        breg[i] = *(const u32x4_t*)(gb + ((long)hy * a.Wh + hx) * a.src_pix_stride + q * 16);
+      }
+    }
+  };
+  auto write_lds = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER_THR; ++i) {
+      const int u = tid + i * 256;
+      const int q = u % A_UNITS_PIX, pix = u / A_UNITS_PIX;
+      *(u32x4_t*)(buf + pix * RA + q * 16) = areg[i];
+    }
+    char* bb = buf + a_bytes;
+#pragma unroll
+    for (int i = 0; i < B_PER_THR_MAX; ++i) {
+      const int u = tid + i * 256;
+      if (u < b_units) {
+        const int q = u % b_units_pix, hp = u / b_units_pix;
+        *(u32x4_t*)(bb + hp * RB + q * 16) = breg[i];
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    issue_loads(t_begin);
+    write_lds(smem);
+  }
+  __syncthreads();
+
+  // lane constants of the transposed reads
+  const int g = lane >> 4, i16 = lane & 15;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int cur = (tile - t_begin) & 1;
+    const bool more = tile + 1 < t_end;
+    if (more) issue_loads(tile + 1);
+    const char* Ab = smem + cur * buf_bytes;
+    const char* Bb = Ab + a_bytes;
+    if constexpr (DT == NINT_BF16) {
+      const int q = i16 >> 2, p8 = (i16 & 3) * 8;
+#pragma unroll 1
+      for (int pr = 0; pr < PR; ++pr) {
+        // pixel -> K-slot: read rd covers pixels rd*16 + 4*g + q of the 32-pixel row segment
+        const int apix0 = pr * 32 + 4 * g + q;
+        u32x4_t af[NTN];
+#pragma unroll
+        for (int i = 0; i < NTN; ++i) {
+          const char* ad = Ab + apix0 * RA + i * 32 + p8;
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + 16 * RA));
+          u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+          af[i] = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
+        }
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+          const int j = j0 + jj;
+          if (j < a.J) {
+            const int tap = j / a.NTC, ct = j - tap * a.NTC;
+            const int tyy = tap / k, txx = tap - tyy * k;
+            const char* bd = Bb + ((pr + tyy) * HWt + txx + 4 * g + q) * RB + ct * 32 + p8;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd + 16 * RB));
+            u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+            const u32x4_t bf = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
+#pragma unroll
+            for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf, acc[i][jj]);
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int pr = 0; pr < PR; ++pr) {
+#pragma unroll 1
+        for (int ks = 0; ks < 2; ++ks) {
+          // 16 pixels per K-step: MFMA m takes pixel 4*m + g of the segment as its K index g
+          const int seg = ks * 16 + g;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            float af[NTN];
+#pragma unroll
+            for (int i = 0; i < NTN; ++i)
+              af[i] = *(const float*)(Ab + (pr * 32 + seg + 4 * m) * RA + (i * 16 + i16) * 4);
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) {
+              const int j = j0 + jj;
+              if (j < a.J) {
+                const int tap = j / a.NTC, ct = j - tap * a.NTC;
+                const int tyy = tap / k, txx = tap - tyy * k;
+                const float bf = *(const float*)(Bb + ((pr + tyy) * HWt + txx + seg + 4 * m) * RB + (ct * 16 + i16) * 4);
+#pragma unroll
+                for (int i = 0; i < NTN; ++i)
+                  acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (more) write_lds(smem + (cur ^ 1) * buf_bytes);
+    __syncthreads();
+  }
+
+  // ---- flush: partial[split][blockIdx.y][j][n'loc 64][c 16]
+  float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * a.J * 1024;
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    const int j = j0 + jj;
+    if (j < a.J) {
+#pragma unroll
+      for (int i = 0; i < NTN; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[(size_t)j * 1024 + (i * 16 + 4 * g + r) * 16 + i16] = acc[i][jj][r];
+    }
+  }
+}
+
+// Fold the split-K slabs into dW (OIHW f32).  One thread per weight element; fixed split order.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ px, const float* __restrict__ ph, float* __restrict__ dW,
+                                    int Cx, int Ch, int k, int NB, int CBx, int CBh, int NTC, int splits_x,
+                                    int splits_h) {
+  const int taps = k * k, Ctot = Cx + Ch;
+  const size_t total = (size_t)4 * Ch * Ctot * taps;
+  const int J = taps * NTC, CW = 16 * NTC;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = i % taps;
+    size_t r = i / taps;
+    const int ic = r % Ctot;
+    const int o = r / Ctot;
+    const int gate = o / Ch, ch = o % Ch;
+    const int np = (ch >> 4) * 64 + gate * 16 + (ch & 15);
+    const int nb = np >> 6, nloc = np & 63;
+    const bool isx = ic < Cx;
+    const int cc = isx ? ic : ic - Cx;
+    const int cb = cc / CW, ct = (cc % CW) >> 4, c16 = cc & 15;
+    const int CB = isx ? CBx : CBh;
+    const int splits = isx ? splits_x : splits_h;
+    const float* part = isx ? px : ph;
+    const int j = tap * NTC + ct;
+    const size_t blk = (size_t)(nb * CB + cb);
+    const size_t stride = (size_t)NB * CB * J * 1024;
+    const size_t off = (blk * J + j) * 1024 + nloc * 16 + c16;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[sp * stride + off];
+    dW[i] = s;
+  }
+}
+
+// db[o] = sum over all pixels of dG[.,o]: grid = (row splits, column groups of 64); fixed order.
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ dG, float* __restrict__ partial,
+                                                             int N, int H, int W, int P, int Hh, int Wh, int Gc) {
+  const int colgrp = blockIdx.y, col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const size_t npix = (size_t)N * H * W;
+  float acc = 0.f;
+  for (size_t pidx = (size_t)blockIdx.x * 4 + sub; pidx < npix; pidx += (size_t)gridDim.x * 4) {
+    const int x = pidx % W;
+    size_t r = pidx / W;
+    const int y = r % H;
+    const int n = r / H;
+    acc += load_elem<DT>(dG, ((((size_t)n * Hh) + (y + P)) * Wh + (x + P)) * Gc + colgrp * 64 + col);
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sub == 0) partial[((size_t)blockIdx.x * gridDim.y + colgrp) * 64 + col] = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ db, int Ch, int Gc, int nrows) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= 4 * Ch) return;
+  const int gate = o / Ch, ch = o % Ch;
+  const int np = (ch >> 4) * 64 + gate * 16 + (ch & 15);
+  float s = 0.f;
+  for (int r = 0; r < nrows; ++r) s += partial[(size_t)r * Gc + np];
+  db[o] = s;
+}
+
+// ------------------------------------------------------------------------------ host side
+struct WgPlan {
+  int NTC, J, JW, NB, CBx, CBh, splits_x, splits_h, tiles_x, tiles_y, ntiles, tps_x, tps_h;
+  size_t off_h, off_db, total_floats;
+  int db_rows;
+};
+
+static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_geom* g, WgPlan* pl) {
+  const int taps = ly->k * ly->k;
+  if (ly->k != 1 && ly->k != 3 && ly->k != 5) return NINT_E_SHAPE;
+  pl->NTC = (taps * 2 <= 20) ? 2 : 1;
+  pl->J = taps * pl->NTC;
+  pl->JW = pl->J <= 20 ? 5 : 7;
+  if (pl->J > 4 * pl->JW) return NINT_E_SHAPE;
+  const int CW = 16 * pl->NTC;
+  if (ly->Cxp % CW || ly->Chp % CW) return NINT_E_SHAPE;
+  pl->NB = 4 * ly->Ch16 / 64;
+  pl->CBx = ly->Cxp / CW;
+  pl->CBh = ly->Chp / CW;
+  const int PR = dtype == NINT_BF16 ? 4 : 2;
+  pl->tiles_x = g ? nint_cdiv(g->W, 32) : 1;
+  pl->tiles_y = g ? nint_cdiv(g->H, PR) : 1;
+  pl->ntiles = g ? N * pl->tiles_x * pl->tiles_y : (1 << 30);
+  if (n_cu <= 0) n_cu = 256;
+  auto splits_for = [&](int CB) {
+    int s = nint_cdiv(3 * n_cu, pl->NB * CB);
+    if (s > pl->ntiles) s = pl->ntiles;
+    if (s < 1) s = 1;
+    return s;
+  };
+  pl->splits_x = splits_for(pl->CBx);
+  pl->splits_h = splits_for(pl->CBh);
+  pl->tps_x = nint_cdiv(pl->ntiles, pl->splits_x);
+  pl->tps_h = nint_cdiv(pl->ntiles, pl->splits_h);
+  // re-derive the split count so that no split is empty
+  pl->splits_x = nint_cdiv(pl->ntiles, pl->tps_x);
+  pl->splits_h = nint_cdiv(pl->ntiles, pl->tps_h);
+  const size_t fx = (size_t)pl->splits_x * pl->NB * pl->CBx * pl->J * 1024;
+  const size_t fh = (size_t)pl->splits_h * pl->NB * pl->CBh * pl->J * 1024;
+  pl->db_rows = 2 * n_cu;
+  pl->off_h = fx;
+  pl->off_db = fx + fh;
+  pl->total_floats = fx + fh + (size_t)pl->db_rows * 4 * ly->Ch16;
+  return NINT_OK;
+}
+
+extern "C" size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, int n_cu) {
+  if (!ly) return 0;
+  WgPlan pl;
+  // upper bound independent of N: splits are capped by 3*n_cu / blocks
+  if (wg_plan(ly, dtype, n_cu, 1, nullptr, &pl) != NINT_OK) return 0;
+  return pl.total_floats * sizeof(float);
+}
+
+template <int DT, int JW>
+static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
+  typedef WgTile<DT> TT;
+  const int p = a.p;
+  const int a_bytes = TT::PR * 32 * TT::RA;
+  const int b_bytes = nint_round_up((TT::PR + 2 * p) * (32 + 2 * p) * TT::rb(a.NTC), 16);
+  const size_t lds = 2 * (size_t)(a_bytes + b_bytes);
+  const int b_units = (TT::PR + 2 * p) * (32 + 2 * p) * (16 * a.NTC * Elem<DT>::ES / 16);
+  if (b_units > 5 * 256) return NINT_E_SHAPE;
+  if (lds > 160 * 1024) return NINT_E_LDS;
+  auto kern = wgrad_kernel<DT, JW>;
+  if (lds > 64 * 1024)
+    NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(splits, nblk), dim3(256), lds, st, a);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG,
+                               const void* x_slab, const void* h_slab, float* dW, float* db, float* partial,
+                               size_t partial_bytes, int n_cu, void* stream) {
+  if (!ly || !g || !dG || !x_slab || !h_slab || !dW || !db || !partial || N <= 0) return NINT_E_ARG;
+  if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
+  WgPlan pl;
+  int rc = wg_plan(ly, dtype, n_cu, N, g, &pl);
+  if (rc != NINT_OK) return rc;
+  if (pl.total_floats * sizeof(float) > partial_bytes) return NINT_E_ARG;
+  const int es = dtype == NINT_BF16 ? 2 : 4;
+  const int Gc = 4 * ly->Ch16;
+  hipStream_t st = (hipStream_t)stream;
+  for (int part = 0; part < 2; ++part) {
+    WgradArgs a = {};
+    a.dG = (const char*)dG;
+    a.dG_pix_stride = Gc * es;
+    a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
+    const int Cp = part == 0 ? ly->Cxp : ly->Chp;
+    a.src = (const char*)(part == 0 ? x_slab : h_slab);
+    a.src_pix_stride = Cp * es;
+    a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
+    a.partial = partial + (part == 0 ? 0 : pl.off_h);
+    a.CB = part == 0 ? pl.CBx : pl.CBh;
+    a.NTC = pl.NTC; a.J = pl.J;
+    a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
+    a.P = g->P; a.Wh = g->Wh;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ntiles = pl.ntiles;
+    a.tiles_per_split = part == 0 ? pl.tps_x : pl.tps_h;
+    const int splits = part == 0 ? pl.splits_x : pl.splits_h;
+    const int nblk = pl.NB * a.CB;
+    if (dtype == NINT_BF16)
+      rc = pl.JW == 5 ? launch_wgrad<NINT_BF16, 5>(a, splits, nblk, st) : launch_wgrad<NINT_BF16, 7>(a, splits, nblk, st);
+    else
+      rc = pl.JW == 5 ? launch_wgrad<NINT_F32, 5>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 7>(a, splits, nblk, st);
+    if (rc != NINT_OK) return rc;
+  }
+  {
+    const size_t total = (size_t)4 * ly->Ch * (ly->Cx + ly->Ch) * ly->k * ly->k;
+    size_t gsz = (total + 255) / 256;
+    if (gsz > 8192) gsz = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, st, partial, partial + pl.off_h, dW,
+                       ly->Cx, ly->Ch, ly->k, pl.NB, pl.CBx, pl.CBh, pl.NTC, pl.splits_x, pl.splits_h);
+    NINT_LAUNCH_CHECK();
+  }
+  {
+    float* dbp = partial + pl.off_db;
+    dim3 grid(pl.db_rows, Gc / 64);
+    if (dtype == NINT_BF16)
+      hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+    else
+      hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+    NINT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nint_cdiv(4 * ly->Ch, 256)), dim3(256), 0, st, dbp, db, ly->Ch, Gc, pl.db_rows);
+    NINT_LAUNCH_CHECK();
+  }
+  return NINT_OK;
+}

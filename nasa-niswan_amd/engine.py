@@ -1,0 +1,296 @@
+"""Host-side engine: owns the device workspaces (allocated through torch's caching allocator,
+sized for 288 GB of HBM: every time step's slabs stay resident) and drives the C-ABI HIP
+library for one ConvLSTM forward / BPTT.  No arithmetic happens in Python or in torch ops."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import NINT_BF16, NINT_F32, NintGeom, NintLayer, NintSeq, check, ptr, stream_ptr
+
+DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
+
+
+def dtype_code(d) -> int:
+    if isinstance(d, int):
+        return d
+    if isinstance(d, torch.dtype):
+        return NINT_BF16 if d == torch.bfloat16 else NINT_F32
+    return DTYPES[str(d).lower()]
+
+
+def _rup(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+@dataclass
+class LayerCfg:
+    Cx: int
+    Ch: int
+    k: int
+
+    def padded(self, kc: int) -> Tuple[int, int, int]:
+        return _rup(self.Cx, kc), _rup(self.Ch, 16), _rup(self.Ch, kc)
+
+
+class Workspace:
+    """All slabs of one (B, T, H, W) problem.  Halo slabs are zero-initialised once; kernels only
+    ever write their interior, so the zero padding of nn.Conv2d (model.py:207-211) is physical."""
+
+    def __init__(self, eng: "SeqEngine", B: int, T: int, H: int, W: int, train: bool, has_init: bool):
+        self.key = (B, T, H, W, train, has_init)
+        self.B, self.T, self.H, self.W, self.train = B, T, H, W, train
+        self.in_use = False
+        dev, es, kc = eng.device, eng.es, eng.kc
+        lib = _lib.load()
+        self.g = NintGeom()
+        check(lib.nint_geom_make(C.byref(self.g), H, W, eng.P), "nint_geom_make")
+        g = self.g
+        halo_px, comp_px = g.Hh * g.Wh, H * W
+        u8 = dict(dtype=torch.uint8, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        Cxp0 = _rup(eng.cfgs[0].Cx, kc)
+        self.xs = torch.zeros(T * B * halo_px * Cxp0 * es, **u8)
+        self.h, self.c, self.gates, self.dG, self.dh, self.dc = [], [], [], [], [], []
+        for cfg in eng.cfgs:
+            Cxp, Ch16, Chp = cfg.padded(kc)
+            self.h.append(torch.zeros((T + 1) * B * halo_px * Chp * es, **u8))
+            self.c.append(torch.zeros((T + 1) * B * comp_px * Chp, **f32))
+            if train:
+                self.gates.append(torch.empty(T * B * comp_px * 4 * Ch16 * es, **u8))
+                self.dG.append(torch.zeros(T * B * halo_px * 4 * Ch16 * es, **u8))
+                self.dh.append(torch.zeros(B * comp_px * Chp, **f32))
+                self.dc.append(torch.zeros(B * comp_px * Chp, **f32))
+        self.dx = None
+        self.Cxp0 = Cxp0
+        self.seq = NintSeq()
+        s = self.seq
+        s.dtype, s.B, s.T, s.L = eng.dt, B, T, len(eng.cfgs)
+        s.need_dx, s.has_init_state, s.n_cu = 0, int(has_init), eng.n_cu
+        s.g = g
+        s.xs = self.xs.data_ptr()
+        for l in range(len(eng.cfgs)):
+            s.h[l] = self.h[l].data_ptr()
+            s.c[l] = self.c[l].data_ptr()
+            if train:
+                s.gates[l] = self.gates[l].data_ptr()
+                s.dG[l] = self.dG[l].data_ptr()
+                s.dh[l] = self.dh[l].data_ptr()
+                s.dc[l] = self.dc[l].data_ptr()
+        if train:
+            s.wg_partial = eng.wg_partial.data_ptr()
+            s.wg_partial_bytes = eng.wg_partial.numel() * 4
+
+    # byte offsets of slab (t) inside the per-layer stacks
+    def h_view(self, eng, l: int, slot: int) -> int:
+        Chp = eng.cfgs[l].padded(eng.kc)[2]
+        return self.h[l].data_ptr() + slot * self.B * self.g.Hh * self.g.Wh * Chp * eng.es
+
+    def c_view(self, eng, l: int, slot: int) -> int:
+        Chp = eng.cfgs[l].padded(eng.kc)[2]
+        return self.c[l].data_ptr() + slot * self.B * self.H * self.W * Chp * 4
+
+
+class SeqEngine:
+    def __init__(self, cfgs: Sequence[LayerCfg], dtype="f32", device="cuda"):
+        if len(cfgs) < 1 or len(cfgs) > _lib.NINT_MAX_LAYERS:
+            raise ValueError("1..8 layers supported")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NintError("the ConvLSTM hot path runs on the MI355X only (device must be cuda); "
+                                 "there is no CPU fallback")
+        self.cfgs = list(cfgs)
+        self.dt = dtype_code(dtype)
+        self.es = 2 if self.dt == NINT_BF16 else 4
+        self.kc = self.lib.nint_kc(self.dt)
+        self.P = max(c.k // 2 for c in cfgs)
+        for c in cfgs:
+            if c.k % 2 == 0:
+                raise ValueError("odd kernel sizes only (padding k//2, model.py:204)")
+        n_cu = C.c_int(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.nint_device_info(C.byref(n_cu), None, None, None, 0), "nint_device_info")
+        self.n_cu = n_cu.value
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        self.Wf, self.Wd, self.bias_p, self.layers = [], [], [], []
+        wg_bytes = 0
+        for cfg in self.cfgs:
+            nbytes = self.lib.nint_packed_weight_bytes(cfg.Cx, cfg.Ch, cfg.k, self.dt, 0)
+            Cxp, Ch16, Chp = cfg.padded(self.kc)
+            self.Wf.append(torch.zeros(nbytes, **u8))
+            self.Wd.append(torch.zeros(nbytes, **u8))
+            self.bias_p.append(torch.zeros(4 * Ch16, dtype=torch.float32, device=self.device))
+            ly = NintLayer()
+            ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k = cfg.Cx, Cxp, cfg.Ch, Ch16, Chp, cfg.k
+            ly.Wf, ly.Wd, ly.bias_p = self.Wf[-1].data_ptr(), self.Wd[-1].data_ptr(), self.bias_p[-1].data_ptr()
+            self.layers.append(ly)
+            wg_bytes = max(wg_bytes, self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu))
+        self._wg_bytes = wg_bytes
+        self._wg_partial = None
+        self.pool: Dict[tuple, List[Workspace]] = {}
+
+    @property
+    def wg_partial(self):
+        if self._wg_partial is None:
+            self._wg_partial = torch.empty(self._wg_bytes // 4 + 16, dtype=torch.float32, device=self.device)
+        return self._wg_partial
+
+    # ------------------------------------------------------------------ weights
+    def pack_weights(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+        st = stream_ptr()
+        for l, cfg in enumerate(self.cfgs):
+            W = weights[l].detach()
+            if W.dtype != torch.float32 or not W.is_contiguous():
+                W = W.float().contiguous()
+            assert tuple(W.shape) == (4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k), W.shape
+            b = biases[l]
+            if b is not None:
+                b = b.detach()
+                if b.dtype != torch.float32 or not b.is_contiguous():
+                    b = b.float().contiguous()
+            check(self.lib.nint_pack_weights(ptr(W), ptr(b), ptr(self.Wf[l]), ptr(self.Wd[l]), ptr(self.bias_p[l]),
+                                             cfg.Cx, cfg.Ch, cfg.k, self.dt, st), "nint_pack_weights")
+
+    # ------------------------------------------------------------------ workspaces
+    def acquire(self, B, T, H, W, train: bool, has_init: bool) -> Workspace:
+        key = (B, T, H, W, train, has_init)
+        for ws in self.pool.setdefault(key, []):
+            if not ws.in_use:
+                ws.in_use = True
+                return ws
+        ws = Workspace(self, B, T, H, W, train, has_init)
+        for l, ly in enumerate(self.layers):
+            ws.seq.layer[l] = ly
+        self.pool[key].append(ws)
+        ws.in_use = True
+        return ws
+
+    @staticmethod
+    def release(ws: Workspace):
+        ws.in_use = False
+
+    # ------------------------------------------------------------------ passes
+    def forward(self, ws: Workspace, x: torch.Tensor, h0: Optional[List[torch.Tensor]] = None,
+                c0: Optional[List[torch.Tensor]] = None):
+        """x (B,T,C,H,W) f32 on the engine's device.  Runs model.py:253-271 (all layers, all steps)."""
+        B, T, Cc, H, W = x.shape
+        assert (B, T, H, W) == (ws.B, ws.T, ws.H, ws.W) and Cc == self.cfgs[0].Cx
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        st = stream_ptr()
+        g = C.byref(ws.g)
+        check(self.lib.nint_pack_btchw(ptr(x), ptr(ws.xs), B, T, Cc, ws.Cxp0, g, self.dt, st), "nint_pack_btchw")
+        if h0 is not None:
+            for l, cfg in enumerate(self.cfgs):
+                Chp = cfg.padded(self.kc)[2]
+                hh = h0[l].detach().float().contiguous().view(B, 1, cfg.Ch, H, W)
+                check(self.lib.nint_pack_btchw(ptr(hh), C.c_void_p(ws.h_view(self, l, 0)), B, 1, cfg.Ch, Chp, g, self.dt, st),
+                      "pack h0")
+                cc = c0[l].detach().float().contiguous()
+                check(self.lib.nint_pack_compact(ptr(cc), C.c_void_p(ws.c_view(self, l, 0)), B, cfg.Ch, Chp, H, W, st),
+                      "pack c0")
+        check(self.lib.nint_seq_fwd(C.byref(ws.seq), st), "nint_seq_fwd")
+
+    def h_last(self, ws: Workspace, l: int, slot: Optional[int] = None) -> torch.Tensor:
+        cfg = self.cfgs[l]
+        Chp = cfg.padded(self.kc)[2]
+        slot = ws.T if slot is None else slot
+        out = torch.empty(ws.B, cfg.Ch, ws.H, ws.W, dtype=torch.float32, device=self.device)
+        check(self.lib.nint_unpack_halo(ptr(ws.h[l]), ptr(out), slot * ws.B, ws.B, cfg.Ch, Chp, C.byref(ws.g), self.dt,
+                                        stream_ptr()), "nint_unpack_halo")
+        return out
+
+    def c_last(self, ws: Workspace, l: int) -> torch.Tensor:
+        cfg = self.cfgs[l]
+        Chp = cfg.padded(self.kc)[2]
+        out = torch.empty(ws.B, cfg.Ch, ws.H, ws.W, dtype=torch.float32, device=self.device)
+        check(self.lib.nint_unpack_compact(C.c_void_p(ws.c_view(self, l, ws.T)), ptr(out), ws.B, cfg.Ch, Chp, ws.H, ws.W,
+                                           stream_ptr()), "nint_unpack_compact")
+        return out
+
+    def head_forward(self, ws: Workspace, w: torch.Tensor, b: Optional[torch.Tensor], slot: Optional[int] = None):
+        """model.py:274: 1x1 conv on the last layer's hidden state of time step ``slot-1``."""
+        l = len(self.cfgs) - 1
+        cfg = self.cfgs[l]
+        Chp = cfg.padded(self.kc)[2]
+        O = w.shape[0]
+        slot = ws.T if slot is None else slot
+        pred = torch.empty(ws.B, O, ws.H, ws.W, dtype=torch.float32, device=self.device)
+        w2 = w.detach().float().contiguous()
+        b2 = None if b is None else b.detach().float().contiguous()
+        check(self.lib.nint_head_fwd(ptr(ws.h[l]), slot * ws.B, ws.B, cfg.Ch, Chp, O, ptr(w2), ptr(b2), ptr(pred),
+                                     C.byref(ws.g), self.dt, stream_ptr()), "nint_head_fwd")
+        return pred
+
+    def head_backward(self, ws: Workspace, w: torch.Tensor, dpred: torch.Tensor):
+        """Writes dL/dh_{T-1} of the last layer into ws.dh[-1]; returns (dw_head, db_head)."""
+        l = len(self.cfgs) - 1
+        cfg = self.cfgs[l]
+        Chp = cfg.padded(self.kc)[2]
+        O = w.shape[0]
+        w2 = w.detach().float().contiguous()
+        dp = dpred.detach().float().contiguous()
+        dw = torch.empty(O, cfg.Ch, dtype=torch.float32, device=self.device)
+        db = torch.empty(O, dtype=torch.float32, device=self.device)
+        check(self.lib.nint_head_bwd(ptr(ws.h[l]), ws.T * ws.B, ws.B, cfg.Ch, Chp, O, ptr(w2), ptr(dp), ptr(ws.dh[l]),
+                                     ptr(dw), ptr(db), C.byref(ws.g), self.dt, stream_ptr()), "nint_head_bwd")
+        return dw.view(O, cfg.Ch, 1, 1), db
+
+    def backward(self, ws: Workspace, need_dx: bool, zero_state_grads: Sequence[int] = ()):
+        """BPTT of model.py:253-271.  Precondition: ws.dh[l], ws.dc[l] hold dL/dh_{T-1}, dL/dc_{T-1}
+        (layers listed in ``zero_state_grads`` are zeroed here).  Returns ([dW_l], [db_l], dx or None)."""
+        assert ws.train
+        for l in zero_state_grads:
+            ws.dh[l].zero_()
+            ws.dc[l].zero_()
+        dWs, dbs = [], []
+        s = ws.seq
+        for l, cfg in enumerate(self.cfgs):
+            dWs.append(torch.empty(4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k, dtype=torch.float32, device=self.device))
+            dbs.append(torch.empty(4 * cfg.Ch, dtype=torch.float32, device=self.device))
+            s.dW[l] = dWs[-1].data_ptr()
+            s.db[l] = dbs[-1].data_ptr()
+        dx = None
+        if need_dx:
+            dx = torch.zeros(ws.T * ws.B * ws.H * ws.W * ws.Cxp0, dtype=torch.float32, device=self.device)
+            s.dx = dx.data_ptr()
+        s.need_dx = int(need_dx)
+        check(self.lib.nint_seq_bwd(C.byref(s), stream_ptr()), "nint_seq_bwd")
+        s.dx = None
+        dx_out = None
+        if need_dx:
+            # compact [T*B][H][W][Cxp0] -> (B,T,C,H,W)
+            C0 = self.cfgs[0].Cx
+            tb = torch.empty(ws.T * ws.B, C0, ws.H, ws.W, dtype=torch.float32, device=self.device)
+            check(self.lib.nint_unpack_compact(ptr(dx), ptr(tb), ws.T * ws.B, C0, ws.Cxp0, ws.H, ws.W, stream_ptr()),
+                  "unpack dx")
+            dx_out = tb.view(ws.T, ws.B, C0, ws.H, ws.W).transpose(0, 1).contiguous()
+        return dWs, dbs, dx_out
+
+    def state_grads(self, ws: Workspace, l: int):
+        """dL/dh_init, dL/dc_init of layer l after backward (has_init_state workspaces)."""
+        cfg = self.cfgs[l]
+        Chp = cfg.padded(self.kc)[2]
+        dh = torch.empty(ws.B, cfg.Ch, ws.H, ws.W, dtype=torch.float32, device=self.device)
+        dc = torch.empty_like(dh)
+        st = stream_ptr()
+        check(self.lib.nint_unpack_compact(ptr(ws.dh[l]), ptr(dh), ws.B, cfg.Ch, Chp, ws.H, ws.W, st), "unpack dh")
+        check(self.lib.nint_unpack_compact(ptr(ws.dc[l]), ptr(dc), ws.B, cfg.Ch, Chp, ws.H, ws.W, st), "unpack dc")
+        return dh, dc
+
+    def set_state_grads(self, ws: Workspace, l: int, dh: Optional[torch.Tensor], dc: Optional[torch.Tensor]):
+        cfg = self.cfgs[l]
+        Chp = cfg.padded(self.kc)[2]
+        st = stream_ptr()
+        for src, dst in ((dh, ws.dh[l]), (dc, ws.dc[l])):
+            if src is None:
+                dst.zero_()
+            else:
+                s2 = src.detach().float().contiguous()
+                check(self.lib.nint_pack_compact(ptr(s2), ptr(dst), ws.B, cfg.Ch, Chp, ws.H, ws.W, st), "pack dstate")

@@ -187,12 +187,12 @@ def adam_step_numpy(p, g, m, v, step: int, lr: float, betas=(0.5, 0.999), eps: f
         m = (m + w1 * (g - m)).astype(np.float32)
     else:
         m = (g - (g - m) * (np.float32(1) - w1)).astype(np.float32)
-    v = (v * np.float32(b2) + (g * g) * np.float32(1 - b2)).astype(np.float32)
+    v = (v * np.float32(b2) + (np.float32(1 - b2) * g) * g).astype(np.float32)   # addcmul: (value*t1)*t2
     bc1 = 1 - b1 ** step
     bc2 = 1 - b2 ** step
     step_size = lr / bc1
     denom = (np.sqrt(v) / np.float32(math.sqrt(bc2)) + np.float32(eps)).astype(np.float32)
-    p = (p - np.float32(step_size) * (m / denom)).astype(np.float32)
+    p = (p + (np.float32(-step_size) * m) / denom).astype(np.float32)             # addcdiv: (value*t1)/t2
     return p, m, v
 
 

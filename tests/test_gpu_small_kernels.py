@@ -1,0 +1,151 @@
+"""GPU parity tests of the HBM-bound kernels around the gate GEMMs, called directly through the
+C ABI: layout conversion, loss, Adam, preproc, the 1x1 head.  Checker = the numpy/torch CPU oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import nasa_niswan_amd as pkg
+    return pkg.load_library()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def geom(lib, H, W, Pd):
+    from nasa_niswan_amd._lib import NintGeom
+    g = NintGeom()
+    assert lib.nint_geom_make(C.byref(g), H, W, Pd) == 0
+    return g
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_pack_unpack_roundtrip_and_zero_halo(lib, dt):
+    B, T, Cc, H, W, Pd = 2, 3, 5, 9, 37, 2
+    g = geom(lib, H, W, Pd)
+    kc = lib.nint_kc(dt)
+    Cp = (Cc + kc - 1) // kc * kc
+    es = 2 if dt else 4
+    x = torch.randn(B, T, Cc, H, W, device="cuda")
+    slab = torch.zeros(T * B * g.Hh * g.Wh * Cp * es, dtype=torch.uint8, device="cuda")
+    assert lib.nint_pack_btchw(P(x), P(slab), B, T, Cc, Cp, C.byref(g), dt, None) == 0
+    out = torch.empty(T * B, Cc, H, W, device="cuda")
+    assert lib.nint_unpack_halo(P(slab), P(out), 0, T * B, Cc, Cp, C.byref(g), dt, None) == 0
+    torch.cuda.synchronize()
+    ref = x.transpose(0, 1).reshape(T * B, Cc, H, W)          # image index = t*B + b
+    if dt:
+        ref = ref.to(torch.bfloat16).float()
+    assert torch.equal(out, ref)
+    view = slab.view(torch.bfloat16 if dt else torch.float32).view(T * B, g.Hh, g.Wh, Cp).float()
+    assert float(view[:, :Pd].abs().max()) == 0 and float(view[:, :, :Pd].abs().max()) == 0
+    assert float(view[:, Pd + H:].abs().max()) == 0 and float(view[:, :, Pd + W:].abs().max()) == 0
+    assert float(view[..., Cc:].abs().max()) == 0
+    # compact slabs
+    c = torch.randn(3, Cc, H, W, device="cuda")
+    cs = torch.empty(3 * H * W * Cp, device="cuda")
+    assert lib.nint_pack_compact(P(c), P(cs), 3, Cc, Cp, H, W, None) == 0
+    c2 = torch.empty_like(c)
+    assert lib.nint_unpack_compact(P(cs), P(c2), 3, Cc, Cp, H, W, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(c, c2)
+
+
+def test_loss_mse_l1_crop_matches_oracle(lib):
+    from oracle import convlstm_oracle as O
+    from nasa_niswan_amd._lib import NINT_LOSS_SCRATCH_FLOATS
+    rng = np.random.default_rng(0)
+    for (Nn, Oc, H, W, oy, ox, Hc, Wc) in [(8, 1, 100, 154, 5, 5, 90, 144), (2, 3, 12, 20, 0, 0, 12, 20), (1, 1, 7, 9, 2, 3, 4, 5)]:
+        pred = torch.from_numpy(rng.standard_normal((Nn, Oc, H, W)).astype(np.float32))
+        y = torch.from_numpy(rng.standard_normal((Nn, Oc, Hc, Wc)).astype(np.float32))
+        pred[0, 0, oy, ox] = y[0, 0, 0, 0]        # exercises sign(0) = 0
+        pd, yd = pred.cuda(), y.cuda()
+        dpred = torch.full_like(pd, 7.0)
+        scratch = torch.zeros(NINT_LOSS_SCRATCH_FLOATS, device="cuda")
+        stats = torch.zeros(5, dtype=torch.float64, device="cuda")
+        assert lib.nint_loss_mse_l1_crop(P(pd), P(yd), P(dpred), P(scratch), P(stats), Nn, Oc, H, W, oy, ox, Hc, Wc, None) == 0
+        torch.cuda.synchronize()
+        pc = pred[:, :, oy:oy + Hc, ox:ox + Wc]
+        ref = float(O.loss_mse_l1(y, pc))
+        assert abs(float(scratch[0]) - ref) <= 2e-6 * abs(ref)
+        gref = torch.zeros_like(pred)
+        gref[:, :, oy:oy + Hc, ox:ox + Wc] = O.loss_mse_l1_grad(y, pc)
+        np.testing.assert_allclose(dpred.cpu().numpy(), gref.numpy(), rtol=1e-5, atol=1e-9)
+        s = stats.cpu().numpy()
+        d = (y - pc).double().numpy()
+        np.testing.assert_allclose(s, [np.sum(d * d), np.abs(d).sum(), y.double().sum(), (y.double() ** 2).sum(), y.numel()], rtol=1e-9)
+        # device-side R2 (replaces the per-batch sklearn call, train.py:114)
+        r2 = 1.0 - s[0] / (s[3] - s[2] ** 2 / s[4])
+        assert abs(r2 - O.r2_score_np(y.numpy(), pc.numpy())) < 1e-9
+
+
+def test_adam_flat_matches_torch_golden(lib):
+    g = np.load(os.path.join(GOLD, "adam.npz"))
+    p = torch.from_numpy(g["p0"].copy()).cuda()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for i, grad in enumerate(g["grads"], 1):
+        gd = torch.from_numpy(grad.copy()).cuda()
+        assert lib.nint_adam_flat(P(p), P(gd), P(m), P(v), p.numel(), float(g["lr"]), 0.5, 0.999, 1e-8, i, 1.0, None) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p.cpu().numpy(), g["p_after"][i - 1], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(m.cpu().numpy(), g["m"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(v.cpu().numpy(), g["v"], rtol=1e-6, atol=1e-12)
+    # grad_scale = 1/world_size folds the DDP average into the step
+    p2 = torch.from_numpy(g["p0"].copy()).cuda()
+    m2, v2 = torch.zeros_like(p2), torch.zeros_like(p2)
+    gd = torch.from_numpy(g["grads"][0] * 4).cuda()
+    assert lib.nint_adam_flat(P(p2), P(gd), P(m2), P(v2), p2.numel(), float(g["lr"]), 0.5, 0.999, 1e-8, 1, 0.25, None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p2.cpu().numpy(), g["p_after"][0], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("levels", [1, 4])
+def test_preproc_fuse_pad_matches_oracle(lib, mode, levels):
+    from oracle import preproc_oracle as PO
+    rng = np.random.default_rng(levels)
+    T, H, W, Hp, Wp = 3, 90, 144, 100, 154
+    shp = (T, levels, H, W)
+    u, v, w = (rng.standard_normal(shp).astype(np.float32) for _ in range(3))
+    pr = np.abs(rng.standard_normal((T, H, W))).astype(np.float32) * 7
+    src = np.abs(rng.standard_normal((T, H, W))).astype(np.float32) * 3
+    Cc = 3 * levels + 2
+    mean = rng.standard_normal(Cc).astype(np.float32)
+    std = (0.5 + rng.random(Cc)).astype(np.float32)
+    ref = PO.preproc_sample(u if levels > 1 else u[:, 0], v if levels > 1 else v[:, 0], w if levels > 1 else w[:, 0],
+                            pr, src, mean, std, (Hp, Wp), "reference" if mode == 0 else "reflect")
+    devs = [torch.from_numpy(a).cuda() for a in (u, v, w, pr, src)]
+    ptrs = (C.c_void_p * 5)(*[t.data_ptr() for t in devs])
+    lev = (C.c_int * 5)(levels, levels, levels, 1, 1)
+    out = torch.empty(T, Cc, Hp, Wp, device="cuda")
+    md, sd = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
+    assert lib.nint_preproc_fuse_pad(ptrs, lev, 5, P(md), P(sd), P(out), T, H, W, Hp, Wp, mode, None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_preproc_padding_golden_13x13(lib):
+    # dataset_config.ipynb:484-502 through the device kernel (reflect mode = the 3-D semantics)
+    from oracle import preproc_oracle as PO
+    x = torch.arange(25, dtype=torch.float32).view(1, 1, 5, 5).cuda()
+    ptrs = (C.c_void_p * 1)(x.data_ptr())
+    lev = (C.c_int * 1)(1)
+    out = torch.empty(1, 1, 13, 13, device="cuda")
+    md, sd = torch.zeros(1, device="cuda"), torch.ones(1, device="cuda")
+    assert lib.nint_preproc_fuse_pad(ptrs, lev, 1, P(md), P(sd), P(out), 1, 5, 5, 13, 13, 1, None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy()[0].astype(np.int64), PO.NOTEBOOK_13x13)
+    # oversize padding is refused like the reference's AttributeError (dataset.py:80,98)
+    assert lib.nint_preproc_fuse_pad(ptrs, lev, 1, P(md), P(sd), P(out), 1, 5, 5, 13, 20, 1, None) == -2
