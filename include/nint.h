@@ -175,8 +175,8 @@ int nint_loss_mse_l1_crop(const float* pred, const float* y, float* dpred, float
 /* ---- optimiser (train.py:71,110) ---------------------------------------------------------------- */
 /* torch.optim.Adam (eps 1e-8, no weight decay / amsgrad) on one flat f32 buffer.
  * grad_scale multiplies g first (1/world_size after the RCCL all-reduce). step is 1-based. */
-int nint_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                   float beta2, float eps, int step, float grad_scale, void* stream);
+int nint_adam_flat(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+                   double beta2, double eps, int step, float grad_scale, void* stream);
 
 /* ---- preproc (dataset.py:520-536, 61-98) --------------------------------------------------------- */
 /* srcs: host array of nsrc device pointers, each (T, lev_i, H, W) f32 with lev[i] levels

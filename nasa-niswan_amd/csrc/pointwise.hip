@@ -450,16 +450,15 @@ extern "C" int nint_loss_mse_l1_crop(const float* pred, const float* y, float* d
 // torch.optim.Adam single-tensor update order (train.py:71,110):
 //   m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                 float* __restrict__ v, size_t n, float step_size, float b1, float b2, float eps,
-                                 float inv_sqrt_bc2_denom, float grad_scale) {
-  const float w1 = 1.f - b1;
+                                 float* __restrict__ v, size_t n, float step_size, float w1, float b2, float w2,
+                                 float eps, float inv_sqrt_bc2_denom, float grad_scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float gr = g[i] * grad_scale;
     float mi = m[i], vi = v[i];
     // torch lerp: a + w*(b-a) for w < 0.5, else b - (b-a)*(1-w)
     mi = (w1 < 0.5f) ? __fadd_rn(mi, __fmul_rn(w1, __fsub_rn(gr, mi)))
                      : __fsub_rn(gr, __fmul_rn(__fsub_rn(gr, mi), 1.f - w1));
-    vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(1.f - b2, gr), gr));   // addcmul: (value*t1)*t2
+    vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(w2, gr), gr));   // addcmul: (value*t1)*t2
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), inv_sqrt_bc2_denom), eps);
     p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(-step_size, mi), denom));          // addcdiv: (value*t1)/t2
     m[i] = mi;
@@ -467,15 +466,17 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
   }
 }
 
-extern "C" int nint_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                              float beta2, float eps, int step, float grad_scale, void* stream) {
+extern "C" int nint_adam_flat(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+                              double beta2, double eps, int step, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || step < 1) return NINT_E_ARG;
   if (n == 0) return NINT_OK;
-  const double bc1 = 1.0 - pow((double)beta1, step);
-  const double bc2 = 1.0 - pow((double)beta2, step);
-  const float step_size = (float)((double)lr / bc1);
+  // scalars in double like torch's Python floats, rounded to f32 once
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bc1);
   const float sqrt_bc2 = (float)sqrt(bc2);
-  hipLaunchKernelGGL(adam_flat_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1, beta2, eps, sqrt_bc2, grad_scale);
+  hipLaunchKernelGGL(adam_flat_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, sqrt_bc2, grad_scale);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }

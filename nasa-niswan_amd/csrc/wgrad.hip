@@ -277,7 +277,7 @@ struct WgPlan {
 static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_geom* g, WgPlan* pl) {
   const int taps = ly->k * ly->k;
   if (ly->k != 1 && ly->k != 3 && ly->k != 5) return NINT_E_SHAPE;
-  pl->NTC = (taps * 2 <= 20) ? 2 : 1;
+  pl->NTC = (taps * 2 <= 20 && ly->Cxp % 32 == 0 && ly->Chp % 32 == 0) ? 2 : 1;
   pl->J = taps * pl->NTC;
   pl->JW = pl->J <= 20 ? 5 : 7;
   if (pl->J > 4 * pl->JW) return NINT_E_SHAPE;

@@ -47,10 +47,11 @@ class _ConvLSTMFn(torch.autograd.Function):
     """x, head_w, head_b, W_0, b_0, ..., W_{L-1}, b_{L-1} -> pred [, seq]"""
 
     @staticmethod
-    def forward(ctx, module, x, head_w, head_b, *wb):
+    def forward(ctx, module, grad_mode, x, head_w, head_b, *wb):
         eng: SeqEngine = module._engine(x.device)
         B, T, _, H, W = x.shape
-        train = torch.is_grad_enabled() and (x.requires_grad or head_w.requires_grad or any(p.requires_grad for p in wb))
+        # grad mode is always off inside Function.forward, so the caller samples it
+        train = grad_mode and any(ctx.needs_input_grad)
         ws = eng.acquire(B, T, H, W, train, False)
         eng.pack_weights(wb[0::2], wb[1::2])
         eng.forward(ws, x)
@@ -63,7 +64,7 @@ class _ConvLSTMFn(torch.autograd.Function):
         if train:
             ctx.eng, ctx.ws, ctx.rel = eng, ws, _Releaser(ws)
             ctx.save_for_backward(head_w)
-            ctx.x_needs_grad = x.requires_grad
+            ctx.x_needs_grad = ctx.needs_input_grad[2]
             ctx.nwb = len(wb)
         else:
             eng.release(ws)
@@ -84,24 +85,24 @@ class _ConvLSTMFn(torch.autograd.Function):
         grads = []
         for l in range(L):
             grads += [dWs[l], dbs[l]]
-        return (None, dx, dw_head, db_head, *grads)
+        return (None, None, dx, dw_head, db_head, *grads)
 
 
 class _CellFn(torch.autograd.Function):
     """x, h, c, W, b -> h', c'   (model.py:216-231)"""
 
     @staticmethod
-    def forward(ctx, module, x, h, c, W, b):
+    def forward(ctx, module, grad_mode, x, h, c, W, b):
         eng: SeqEngine = module._engine(x.device)
         B, _, H, Wd = x.shape
-        train = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, h, c, W, b))
+        train = grad_mode and any(ctx.needs_input_grad)
         ws = eng.acquire(B, 1, H, Wd, train, True)
         eng.pack_weights([W], [b])
         eng.forward(ws, x.unsqueeze(1), [h], [c])
         h1, c1 = eng.h_last(ws, 0), eng.c_last(ws, 0)
         if train:
             ctx.eng, ctx.ws, ctx.rel = eng, ws, _Releaser(ws)
-            ctx.x_needs_grad = x.requires_grad
+            ctx.x_needs_grad = ctx.needs_input_grad[2]
             ctx.has_bias = b is not None
         else:
             eng.release(ws)
@@ -116,7 +117,7 @@ class _CellFn(torch.autograd.Function):
         ctx.rel.release()
         if dx is not None:
             dx = dx[:, 0]
-        return None, dx, dh0, dc0, dWs[0], (dbs[0] if ctx.has_bias else None)
+        return None, None, dx, dh0, dc0, dWs[0], (dbs[0] if ctx.has_bias else None)
 
 
 # ------------------------------------------------------------------------------ modules
@@ -150,7 +151,7 @@ class ConvLSTMCell(nn.Module):
     def forward(self, x, hidden_state):
         h, c = hidden_state
         _require_cuda(x, "ConvLSTMCell")
-        return _CellFn.apply(self, x, h, c, self.conv.weight, self.conv.bias)
+        return _CellFn.apply(self, torch.is_grad_enabled(), x, h, c, self.conv.weight, self.conv.bias)
 
 
 class ConvLSTM(nn.Module):
@@ -185,4 +186,4 @@ class ConvLSTM(nn.Module):
         wb = []
         for cell in self.layers:
             wb += [cell.conv.weight, cell.conv.bias]
-        return _ConvLSTMFn.apply(self, x, self.conv.weight, self.conv.bias, *wb)
+        return _ConvLSTMFn.apply(self, torch.is_grad_enabled(), x, self.conv.weight, self.conv.bias, *wb)
