@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/sec of the Smart-NINT ConvLSTM on synthetic 90x144x20
+grids at seq_len=12 (BASELINE.json metric / configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch resident in HBM: pack -> ConvLSTM forward
+(12 steps x 3 layers) -> 1x1 head -> crop+MSE+L1 -> BPTT (pointwise, dgrad, wgrad) -> [RCCL
+all-reduce of the flat gradient bucket] -> Adam.  Rank 0 prints ONE JSON line.
+
+Workload (config.workload = "cfg1-20level"): ConvLSTM(62, (64,32,16), (5,3,3)), head out 20,
+X (B,12,62,100,154) = 3 met fields x 20 levels + precipitation + emission on the 90x144 GISS grid
+with the reference's 5-cell halo (launcher.sh:24), y (B,20,90,144); bf16 storage, f32 accumulate,
+f32 master weights; B = 8 per GPU (launcher.sh:25), weak scaling across GPUs.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (C_in, hidden, kernels, out_channels, T, Hp, Wp, halo, grid)
+    "cfg1-20level": (62, (64, 32, 16), (5, 3, 3), 20, 12, 100, 154, (5, 5), (90, 144)),
+    "cfg1-refpinned": (5, (64, 32, 16), (5, 3, 3), 1, 12, 100, 154, (5, 5), (90, 144)),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
+
+
+def fwd_flops_per_sample(C, hidden, ks, out, T, Hp, Wp):
+    """F_fwd = 2*Hp*Wp*T*sum_l k^2 (Cin+Ch) 4Ch (+ head)."""
+    f, cin = 0, C
+    for ch, k in zip(hidden, ks):
+        f += k * k * (cin + ch) * 4 * ch
+        cin = ch
+    return 2 * Hp * Wp * (T * f + hidden[-1] * out)
+
+
+def time_kernel(fn, iters, stream):
+    """average device time of `fn` (one launch sequence on `stream`) with HIP events, in ms"""
+    fn()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(iters):
+        fn()
+    ev1.record(stream)
+    ev1.synchronize()
+    return ev0.elapsed_time(ev1) / iters
+
+
+def cpu_baseline(name, steps=3):
+    """The CPU oracle (plain PyTorch CPU ops = the ATen path the reference takes on CPU) timed on
+    this box's host cores on a bounded sample of the same workload: B=2, f32, 1 warm-up + `steps`
+    timed train steps.  Reported, never the target."""
+    from oracle import convlstm_oracle as O      # checker / baseline only -- never on the product path
+    C, hidden, ks, out, T, Hp, Wp, halo, grid = WORKLOADS[name]
+    B = 2
+    threads = torch.get_num_threads()
+    params = O.synth_params(C, hidden, ks, len(hidden), out_channels=out, seed=0)
+    import numpy as np
+    rng = np.random.default_rng(0)
+    X = torch.from_numpy(rng.standard_normal((B, T, C, Hp, Wp)).astype("float32"))
+    y = torch.from_numpy(rng.standard_normal((B, out, grid[0], grid[1])).astype("float32"))
+    state = None
+    params, state, *_ = O.train_step(params, state, X, y, lr=1e-3, halo=halo)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        params, state, *_ = O.train_step(params, state, X, y, lr=1e-3, halo=halo)
+    dt = time.perf_counter() - t0
+    return {"value": round(B * steps / dt, 4), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{name} at B={B}, f32, {steps} timed train steps after 1 warm-up ({dt:.1f} s of CPU work)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="cfg1-20level", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL on ROCm
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import nasa_niswan_amd as pkg
+    from nasa_niswan_amd.trainer import FusedTrainer
+    pkg.load_library()
+
+    C, hidden, ks, out, T, Hp, Wp, halo, grid = WORKLOADS[args.workload]
+    B = args.batch
+    torch.manual_seed(0)                                    # identical init on every rank (utils.py:77-88)
+    model = pkg.ConvLSTM(C, list(hidden), list(ks), len(hidden), out_channels=out, compute_dtype=args.dtype).to(dev)
+    trainer = FusedTrainer(model, lr=1e-3, betas=(0.5, 0.999), halo=halo)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)   # each rank its own shard of synthetic data
+    X = torch.randn(B, T, C, Hp, Wp, device=dev, generator=gen)
+    y = torch.randn(B, out, grid[0], grid[1], device=dev, generator=gen)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(X, y)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(X, y)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+
+    # ---- roofline of the dominant kernel: the layer-0 fused gate kernel (conv_igemm, LSTM epilogue)
+    roof = None
+    if rank == 0:
+        import ctypes as Ct
+        eng = model._engine(dev)
+        ws = eng.acquire(B, T, Hp, Wp, True, False)
+        lib = pkg.load_library()
+        ly, g = eng.layers[0], ws.g
+        st = torch.cuda.current_stream()
+        # t = 1 step of layer 0: x slab image B.., h_prev = slab 1, c_prev = slot 1 -> writes slot 2
+        kc, es = eng.kc, eng.es
+        halo_px, comp_px = g.Hh * g.Wh, Hp * Wp
+        xs = ws.xs.data_ptr() + 1 * B * halo_px * ly.Cxp * es
+        hs = B * halo_px * ly.Chp * es
+        cs = B * comp_px * ly.Chp * 4
+        gs = B * comp_px * 4 * ly.Ch16 * es
+
+        def one():
+            rc = lib.nint_cell_fwd(Ct.byref(ly), Ct.byref(g), eng.dt, B, Ct.c_void_p(xs), Ct.c_void_p(ws.h[0].data_ptr() + hs),
+                                   Ct.c_void_p(ws.c[0].data_ptr() + cs), Ct.c_void_p(ws.h[0].data_ptr() + 2 * hs),
+                                   Ct.c_void_p(ws.c[0].data_ptr() + 2 * cs), Ct.c_void_p(ws.gates[0].data_ptr() + gs),
+                                   Ct.c_void_p(st.cuda_stream))
+            assert rc == 0
+        ms = time_kernel(one, 50, st)
+        eng.release(ws)
+        k0, ch0 = ks[0], hidden[0]
+        flops = 2.0 * B * Hp * Wp * k0 * k0 * (C + ch0) * 4 * ch0          # algorithmic, per launch
+        achieved = flops / (ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        roof = {"kernel": "conv_igemm_kernel<LSTM epilogue> layer 0 (B images, one time step)", "bound": "mfma",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
+
+    samples = world * B * args.steps
+    value = samples / elapsed
+    if rank == 0:
+        f_train = 3 * fwd_flops_per_sample(C, hidden, ks, out, T, Hp, Wp)
+        line = {
+            "metric": "training samples/sec (90x144x20 grid, seq_len=12)",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": args.workload, "in_channels": C, "hidden": list(hidden), "kernels": list(ks),
+                       "out_channels": out, "seq_len": T, "padded_grid": [Hp, Wp], "grid": list(grid),
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "whole_step_tflops": round(value * f_train / 1e12, 2),
+            "whole_step_mfma_frac": round(value * f_train / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4),
+            "final_loss": round(final_loss, 5),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

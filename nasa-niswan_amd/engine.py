@@ -228,7 +228,7 @@ class SeqEngine:
                                      C.byref(ws.g), self.dt, stream_ptr()), "nint_head_fwd")
         return pred
 
-    def head_backward(self, ws: Workspace, w: torch.Tensor, dpred: torch.Tensor):
+    def head_backward(self, ws: Workspace, w: torch.Tensor, dpred: torch.Tensor, dw_out=None, db_out=None):
         """Writes dL/dh_{T-1} of the last layer into ws.dh[-1]; returns (dw_head, db_head)."""
         l = len(self.cfgs) - 1
         cfg = self.cfgs[l]
@@ -236,15 +236,17 @@ class SeqEngine:
         O = w.shape[0]
         w2 = w.detach().float().contiguous()
         dp = dpred.detach().float().contiguous()
-        dw = torch.empty(O, cfg.Ch, dtype=torch.float32, device=self.device)
-        db = torch.empty(O, dtype=torch.float32, device=self.device)
+        dw = dw_out if dw_out is not None else torch.empty(O, cfg.Ch, dtype=torch.float32, device=self.device)
+        db = db_out if db_out is not None else torch.empty(O, dtype=torch.float32, device=self.device)
         check(self.lib.nint_head_bwd(ptr(ws.h[l]), ws.T * ws.B, ws.B, cfg.Ch, Chp, O, ptr(w2), ptr(dp), ptr(ws.dh[l]),
                                      ptr(dw), ptr(db), C.byref(ws.g), self.dt, stream_ptr()), "nint_head_bwd")
         return dw.view(O, cfg.Ch, 1, 1), db
 
-    def backward(self, ws: Workspace, need_dx: bool, zero_state_grads: Sequence[int] = ()):
+    def backward(self, ws: Workspace, need_dx: bool, zero_state_grads: Sequence[int] = (),
+                 dW_out: Optional[Sequence[torch.Tensor]] = None, db_out: Optional[Sequence[torch.Tensor]] = None):
         """BPTT of model.py:253-271.  Precondition: ws.dh[l], ws.dc[l] hold dL/dh_{T-1}, dL/dc_{T-1}
-        (layers listed in ``zero_state_grads`` are zeroed here).  Returns ([dW_l], [db_l], dx or None)."""
+        (layers listed in ``zero_state_grads`` are zeroed here).  Returns ([dW_l], [db_l], dx or None).
+        ``dW_out`` / ``db_out``: f32 contiguous destinations (e.g. views of a flat gradient bucket)."""
         assert ws.train
         for l in zero_state_grads:
             ws.dh[l].zero_()
@@ -252,8 +254,13 @@ class SeqEngine:
         dWs, dbs = [], []
         s = ws.seq
         for l, cfg in enumerate(self.cfgs):
-            dWs.append(torch.empty(4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k, dtype=torch.float32, device=self.device))
-            dbs.append(torch.empty(4 * cfg.Ch, dtype=torch.float32, device=self.device))
+            if dW_out is not None:
+                dWs.append(dW_out[l])
+                dbs.append(db_out[l])
+                assert dWs[-1].numel() == 4 * cfg.Ch * (cfg.Cx + cfg.Ch) * cfg.k * cfg.k and dWs[-1].is_contiguous()
+            else:
+                dWs.append(torch.empty(4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k, dtype=torch.float32, device=self.device))
+                dbs.append(torch.empty(4 * cfg.Ch, dtype=torch.float32, device=self.device))
             s.dW[l] = dWs[-1].data_ptr()
             s.db[l] = dbs[-1].data_ptr()
         dx = None

@@ -1,0 +1,119 @@
+"""One batch of the reference fit loop (train.py:92-114) as a fixed sequence of HIP launches.
+
+    X.cuda(), y.cuda()                      -> inputs already on device
+    pred = generator(X)                     -> nint_pack_btchw + nint_seq_fwd + nint_head_fwd
+    pred[:, :, 5:95, 5:149].squeeze()       -> crop folded into the loss kernel (index math)
+    MSELoss(y,pred) + L1Loss(y,pred)        -> nint_loss_mse_l1_crop (also emits d loss/d pred)
+    zero_grad; loss.backward()              -> nint_head_bwd + nint_seq_bwd (grads overwrite the bucket)
+    [DDP]                                   -> ONE RCCL all-reduce of the flat gradient bucket
+    optimizer.step()                        -> nint_adam_flat (1/world folded in)
+    loss.item(); r2_score(...cpu())         -> device-side accumulators, read once per epoch
+
+No autograd graph, no per-kernel Python, no host synchronisation inside the step."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import NINT_LOSS_SCRATCH_FLOATS, check, ptr, stream_ptr
+from .model import ConvLSTM
+from .optim import FlatParams, FusedAdam
+
+
+class FusedTrainer:
+    def __init__(self, model: ConvLSTM, lr: float = 1e-3, betas=(0.5, 0.999), eps: float = 1e-8,
+                 halo: Tuple[int, int] = (5, 5), process_group=None, distributed: Optional[bool] = None):
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.NintError("FusedTrainer needs the model on the MI355X (cuda)")
+        self.model = model
+        self.device = dev
+        self.flat = FlatParams(model)
+        self.optimizer = FusedAdam(self.flat, lr=lr, betas=betas, eps=eps)
+        self.halo = tuple(halo)
+        self.lib = _lib.load()
+        self.scratch = torch.zeros(NINT_LOSS_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(5, dtype=torch.float64, device=dev)   # sum d^2, sum |d|, sum y, sum y^2, n
+        self._dpred = None
+        import torch.distributed as dist
+        self.dist = dist
+        self.pg = process_group
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.world = dist.get_world_size(process_group) if distributed else 1
+        L = model.num_layers
+        self._dW = [self.flat.grad_view(2 * l) for l in range(L)]
+        self._db = [self.flat.grad_view(2 * l + 1) for l in range(L)]
+        self._dw_head = self.flat.grad_view(2 * L)
+        self._db_head = self.flat.grad_view(2 * L + 1)
+        if self.world > 1:
+            # identical initial weights on every rank (the reference seeds identically, utils.py:77-88)
+            dist.broadcast(self.flat.data, src=0, group=process_group)
+
+    # ------------------------------------------------------------------ pieces
+    def forward_loss(self, X: torch.Tensor, y: torch.Tensor, train: bool = True):
+        m = self.model
+        eng = m._engine(self.device)
+        B, T, _, H, W = X.shape
+        ws = eng.acquire(B, T, H, W, train, False)
+        wb_w = [c.conv.weight for c in m.layers]
+        wb_b = [c.conv.bias for c in m.layers]
+        eng.pack_weights(wb_w, wb_b)
+        eng.forward(ws, X)
+        pred = eng.head_forward(ws, m.conv.weight, m.conv.bias)
+        O = pred.shape[1]
+        Hc, Wc = y.shape[-2], y.shape[-1]
+        yv = y.detach().float().contiguous()
+        assert yv.numel() == B * O * Hc * Wc, "target must be (B,[O,]Hc,Wc)"
+        dpred = None
+        if train:
+            if self._dpred is None or self._dpred.shape != pred.shape:
+                self._dpred = torch.empty_like(pred)
+            dpred = self._dpred
+        check(self.lib.nint_loss_mse_l1_crop(ptr(pred), ptr(yv), ptr(dpred), ptr(self.scratch), ptr(self.stats),
+                                             B, O, H, W, self.halo[0], self.halo[1], Hc, Wc, stream_ptr()),
+              "nint_loss_mse_l1_crop")
+        return eng, ws, pred, dpred
+
+    def step(self, X: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """One optimisation step; returns the loss as a 0-dim DEVICE tensor (no sync)."""
+        eng, ws, pred, dpred = self.forward_loss(X, y, True)
+        L = self.model.num_layers
+        eng.head_backward(ws, self.model.conv.weight, dpred, dw_out=self._dw_head, db_out=self._db_head)
+        for l in range(L):
+            ws.dc[l].zero_()
+            if l < L - 1:
+                ws.dh[l].zero_()
+        eng.backward(ws, False, dW_out=self._dW, db_out=self._db)
+        eng.release(ws)
+        if self.world > 1:
+            self.dist.all_reduce(self.flat.grad, op=self.dist.ReduceOp.SUM, group=self.pg)   # RCCL over xGMI
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        return self.scratch[0]
+
+    @torch.no_grad()
+    def evaluate(self, X: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """Forward + loss only (val_loop, utils.py:52-75); accumulates the R2 statistics."""
+        eng, ws, pred, _ = self.forward_loss(X, y, False)
+        eng.release(ws)
+        return pred
+
+    # ------------------------------------------------------------------ epoch statistics
+    def reset_stats(self):
+        self.stats.zero_()
+
+    def epoch_stats(self):
+        """One device->host read per epoch.  Returns (mean loss, pooled R2) over everything accumulated
+        since reset_stats(); under DDP the five sums are all-reduced first."""
+        s = self.stats.clone()
+        if self.world > 1:
+            self.dist.all_reduce(s, op=self.dist.ReduceOp.SUM, group=self.pg)
+        s2, s1, sy, syy, n = (float(v) for v in s.cpu())
+        if n == 0:
+            return float("nan"), float("nan")
+        loss = s2 / n + s1 / n
+        ss_tot = syy - sy * sy / n
+        return loss, 1.0 - s2 / ss_tot if ss_tot > 0 else float("nan")
