@@ -1,0 +1,116 @@
+"""GPU tests of the fit-loop level: fused trainer vs the oracle's fit-loop step on the reference's
+goldens, the reference-style autograd loop with FusedAdam, device preproc through the dataset,
+and the train.py shell end to end (artefacts, checkpoint interchange)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import nasa_niswan_amd as p
+    p.load_library()
+    return p
+
+
+def test_fused_trainer_matches_reference_fit_loop_cfg0(pkg):
+    """BASELINE configs[0]: 1-layer ConvLSTM, 32x32, 4 channels, seq_len 4, batch 2 -- three optimiser
+    steps against the goldens produced by the reference model.py + torch.optim.Adam."""
+    from nasa_niswan_amd.trainer import FusedTrainer
+    g = np.load(os.path.join(GOLD, "cfg0_train.npz"))
+    params = {k[len("params0."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("params0.")}
+    net = pkg.ConvLSTM(4, [8], [3], 1).cuda()
+    net.load_state_dict(params)
+    tr = FusedTrainer(net, lr=float(g["lr"]), betas=tuple(g["betas"]), halo=(0, 0))
+    X, y = torch.from_numpy(g["X"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    for step in (1, 2, 3):
+        loss = float(tr.step(X, y))
+        print(f"  step {step}: loss {loss:.7f} golden {float(g[f'loss{step}']):.7f}")
+        assert abs(loss - float(g[f"loss{step}"])) < 2e-6
+        if step == 1:
+            for i, (k, p) in enumerate(net.named_parameters()):
+                e = float((tr.flat.grad_view(i).cpu() - torch.from_numpy(g["grad." + k])).abs().max())
+                assert e <= 1e-3 * float(np.abs(g["grad." + k]).max()) + 1e-7, (k, e)
+    # weights after 3 Adam steps: lr=1e-4, so a last-bit sign flip of a ~0 gradient moves a weight by <= 2e-4 per step
+    for k, v in net.state_dict().items():
+        d = (v.cpu() - torch.from_numpy(g["params3." + k])).abs()
+        print(f"  {k}: max |dW| {float(d.max()):.2e}, mean {float(d.mean()):.2e}")
+        assert float(d.max()) <= 6.5e-4 and float(d.mean()) <= 2e-6
+    loss_e, r2_e = tr.epoch_stats()
+    assert abs(loss_e - np.mean([float(g[f"loss{s}"]) for s in (1, 2, 3)])) < 1e-5 and r2_e < 0.5
+
+
+def test_reference_style_autograd_loop_equals_fused_trainer(pkg):
+    from nasa_niswan_amd.optim import FlatParams, FusedAdam
+    from nasa_niswan_amd.trainer import FusedTrainer
+    from oracle import convlstm_oracle as O
+    params = O.synth_params(5, [16, 8, 8], [5, 3, 3], 3, seed=9)
+    X, y = O.synth_batch(2, 3, 5, 20, 28, (10, 18), seed=9)
+    Xd, yd = X.cuda(), y.cuda()
+    a = pkg.ConvLSTM(5, [16, 8, 8], [5, 3, 3], 3).cuda(); a.load_state_dict(params)
+    b = pkg.ConvLSTM(5, [16, 8, 8], [5, 3, 3], 3).cuda(); b.load_state_dict(params)
+    tr = FusedTrainer(a, lr=1e-3, betas=(0.5, 0.999), halo=(5, 5))
+    opt = FusedAdam(FlatParams(b), lr=1e-3, betas=(0.5, 0.999))
+    l1, l2 = torch.nn.MSELoss(), torch.nn.L1Loss()
+    for _ in range(3):
+        la = float(tr.step(Xd, yd))
+        pred = b(Xd)[:, :, 5:15, 5:23].squeeze()                 # the reference loop body, train.py:96-110
+        loss = l1(yd, pred) + l2(yd, pred)
+        opt.zero_grad(); loss.backward(); opt.step()
+        assert abs(la - float(loss)) < 1e-6
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert float((va - vb).abs().max()) < 1e-6, k
+
+
+def test_dataset_device_batch_matches_oracle_preproc(pkg):
+    from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
+    from oracle import preproc_oracle as PO
+    for levels, mode in ((1, "reference"), (3, "reflect")):
+        ds = SyntheticE33OMA_CRNN("train", padding=(100, 154), in_channels=3 * levels + 2, sequence_length=5,
+                                  levels=levels, n_steps=30, pad_mode=mode, device="cuda")
+        X, y = ds.device_batch([0, 7])
+        torch.cuda.synchronize()
+        assert X.shape == (2, 5, 3 * levels + 2, 100, 154)       # dataset_config.ipynb:712 (X: (T,5,100,154))
+        for b, idx in enumerate((0, 7)):
+            (u, v, w, pr, src), yr = ds.window(idx)
+            ref = PO.preproc_sample(u if levels > 1 else u[:, 0], v if levels > 1 else v[:, 0], w if levels > 1 else w[:, 0],
+                                    pr, src, ds.X_mean, ds.X_std, (100, 154), mode)
+            np.testing.assert_allclose(X[b].cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+            yref = (yr - ds.y_mean) / ds.y_std
+            np.testing.assert_allclose(y[b].cpu().numpy(), yref[0] if levels == 1 else yref, rtol=1e-6, atol=1e-6)
+        Xi, yi = ds[7]
+        assert torch.equal(Xi, X[1]) and yi.shape == ((90, 144) if levels == 1 else (levels, 90, 144))
+
+
+def test_train_py_end_to_end(pkg, tmp_path, monkeypatch):
+    from nasa_niswan_amd import train as T
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    snap = tmp_path / "snap"
+    argv = ["--model", "LSTM-test", "--in-channels", "5", "--hidden-channels", "8", "8", "--kernel-size", "3", "3",
+            "--num-layers", "2", "--sequence-length", "4", "--num-epochs", "10", "--input-size", "100", "154",
+            "--batch-size", "4", "--learning-rate", "1e-3", "--scheduler-config", "4", "0.5", "--snapshot-dir", str(snap),
+            "--synthetic-steps", "36", "--dtype", "f32"]
+    logger = T.main(T.get_arguments(argv))
+    assert len(logger["MSELoss"]) == 10 and all(np.isfinite(logger["MSELoss"]))
+    assert logger["MSELoss"][-1] < logger["MSELoss"][0]                     # it learns
+    with open(snap / "logger.npy", "rb") as f:                               # three stacked np.save (train.py:138-142)
+        a, b, c = np.load(f), np.load(f), np.load(f)
+    assert a.shape == b.shape == c.shape == (10,)
+    ck = torch.load(snap / "epoch-010" / "generator.pth.tar", weights_only=True)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "learning_rate", "epoch"} and ck["epoch"] == 10
+    assert abs(ck["learning_rate"][0] - 1e-3 * 0.25) < 1e-12                 # StepLR(4, 0.5) after 10 epochs
+    assert list(ck["model_state_dict"]) == ["layers.0.conv.weight", "layers.0.conv.bias", "layers.1.conv.weight",
+                                            "layers.1.conv.bias", "conv.weight", "conv.bias"]
+    # resume: weights + Adam moments restored, LR forced to the CLI value (utils.py:34-50)
+    logger2 = T.main(T.get_arguments(argv[:-4] + ["--synthetic-steps", "36", "--dtype", "f32", "--use-checkpoint",
+                                                   "--restore-from", str(snap / "epoch-010"), "--num-epochs", "1"]))
+    assert logger2["MSELoss"][0] < logger["MSELoss"][0]
