@@ -7,43 +7,47 @@
 // GEMM view: M = pixels (16 consecutive x per MFMA row tile), N = output columns
 // (gate channels / cat channels), K = (64-byte channel chunk, tap).  The zero padding of
 // nn.Conv2d is physical: sources are halo slabs whose border is kept zero, so no tap is ever
-// predicated.  A workgroup owns TH=8 rows x 16 columns of pixels:
-//   - its (8+2p) x (16+2p) halo tile is staged in LDS one or more channel chunks at a time,
-//     laid out [chunk][halo pixel][64 B] so that every A fragment read is one contiguous
-//     1 KiB ds_read_b128 (conflict free), re-used by all k*k taps and all N waves;
-//   - weights are pre-packed in MFMA fragment order, streamed L2 -> registers -> LDS in
-//     double-buffered groups (one barrier per group), shared by the M waves;
+// predicated.  A workgroup (4 waves) owns 8 rows x 16 columns of pixels:
+//   - A: its (8+2p) x (16+2p) halo tile is staged in LDS, several channel chunks per fill, laid
+//     out [chunk][g][halo pixel][16 B] (g = the lane group that consumes those 16 bytes), so
+//     every A fragment read is a lane-linear ds_read_b128 (no bank conflicts) and a tap is a
+//     constant address offset.  The image is read-only between fills: NO barrier in the K loop.
+//   - B: weights are pre-packed in MFMA fragment order, so a wave's B fragment is one fully
+//     coalesced 1 KiB global load straight into VGPRs (L2-resident, prefetched one K-step ahead).
+//     Waves never share B: the 4 waves split the work as WN column groups x WK K-slices, every
+//     wave computing 8 row tiles x NTW column tiles (24-32 MFMAs per 8 LDS reads).  K-slices are
+//     summed through LDS once at the end (narrow-N layers: layer 3, dgrad of layer 1).
 //   - the i,f,g,o tiles of one hidden channel sit in the same lane (column order
 //     n' = (cblock*4+gate)*16+col), so the LSTM epilogue needs no cross-lane traffic.
 #include "nint_common.h"
 
 enum { EPI_LSTM = 0, EPI_DGRAD = 1 };
 
-template <int DT, int EPI, int WM, int WN, int MT, int NTW>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int NTH = 64 * WM * WN;
-  constexpr int TH = WM * MT;
-  constexpr int NTWG = WN * NTW;                       // n-tiles per workgroup
-  constexpr int KG = (4 * WM + NTW - 1) / NTW;         // K-steps per weight group (~4 KiB per wave)
-  constexpr int BU = (KG * NTWG * 64 + NTH - 1) / NTH; // 16-byte units of a weight group per thread
-  constexpr int BG_BYTES = KG * NTWG * 1024;
+constexpr int MT = 8;   // row tiles per wave = rows of the pixel tile
+
+template <int DT, int EPI, int WN, int WK, int NTW>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(WN * WK == 4, "four waves per workgroup");
   static_assert(EPI != EPI_LSTM || NTW % 4 == 0, "LSTM epilogue needs the 4 gate tiles in one wave");
+  constexpr int NTH = 256;
+  constexpr int NTWG = WN * NTW;   // n-tiles per workgroup
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Abuf = smem;
-  char* Bbuf = smem + a.a_bytes;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave % WN, wk = wave / WN;
   int tile = blockIdx.x;
   const int tx = tile % a.tiles_x; tile /= a.tiles_x;
   const int ty = tile % a.tiles_y;
   const int img = tile / a.tiles_y;
-  const int nt0 = a.nt_begin + blockIdx.y * NTWG;
-  const int y0 = ty * TH, x0 = tx * 16;
+  const int nt0 = a.nt_begin + blockIdx.y * NTWG + wn * NTW;   // first n-tile of this wave
+  const int y0 = ty * MT, x0 = tx * 16;
   const int p = a.p, k = a.k, taps = a.taps;
-  const int HWt = 16 + 2 * p;            // halo tile width
-  const int NHP = (TH + 2 * p) * HWt;    // halo tile pixels
+  const int HWt = 16 + 2 * p;                  // halo tile width
+  const int NHP = (MT + 2 * p) * HWt;          // halo tile pixels
+  const int NHPp = a.nhp_pad;                  // padded to a multiple of 16 pixels (planes stay bank aligned)
+  const int plane = NHPp * 16;                 // bytes of one g-plane
+  const int chunk_bytes = 4 * plane;
 
   f32x4_t acc[MT][NTW];
 #pragma unroll
@@ -57,92 +61,96 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
   const char* base1 = a.src1 ? a.src1 + (long)img * a.img_stride1 +
                                    ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.pix_stride1
                              : nullptr;
-  const int a_lane_off = (lane & 15) * 64 + (lane >> 4) * 16;
+  const int a_lane_off = (lane >> 4) * plane + (lane & 15) * 16;
+  const char* Bwave = a.Bp + (size_t)nt0 * 1024 + lane * 16;
+  const size_t bstep = (size_t)a.NTt * 1024;   // bytes between consecutive K-steps in Bp
 
   for (int c_begin = 0; c_begin < nchunks; c_begin += a.cpf) {
     const int c_cnt = min(a.cpf, nchunks - c_begin);
+    if (c_begin > 0) __syncthreads();          // every wave is done reading the previous image
     // ---- stage the halo tile for chunks [c_begin, c_begin+c_cnt): global -> regs -> LDS ----
-    // (the barrier that ended the previous fill's last group already freed Abuf and Bbuf)
-    const int a_units = c_cnt * NHP * 4;
-    for (int u = tid; u < a_units; u += NTH) {
-      const int q = u & 3;
-      const int hpc = u >> 2;
-      const int cl = hpc / NHP;
-      const int hp = hpc - cl * NHP;
-      const int hy = hp / HWt;
-      const int hx = hp - hy * HWt;
-      const int c = c_begin + cl;
-      const char* src = (c < a.nchunk0)
-          ? base0 + ((long)hy * a.Wh + hx) * a.pix_stride0 + c * 64 + q * 16
-          : base1 + ((long)hy * a.Wh + hx) * a.pix_stride1 + (c - a.nchunk0) * 64 + q * 16;
-      *(u32x4_t*)(Abuf + (size_t)u * 16) = *(const u32x4_t*)src;
+    const int a_units = c_cnt * 4 * NHPp;
+    constexpr int FB = 8;                      // loads in flight per thread
+    for (int u0 = tid; u0 < a_units; u0 += NTH * FB) {
+      u32x4_t fr[FB];
+#pragma unroll
+      for (int f = 0; f < FB; ++f) {
+        const int u = u0 + f * NTH;
+        const int hp = u % NHPp;
+        const int cq = u / NHPp;               // cl*4 + q
+        if (u < a_units && hp < NHP) {
+          const int q = cq & 3, cl = cq >> 2;
+          const int hy = hp / HWt;
+          const int hx = hp - hy * HWt;
+          const int c = c_begin + cl;
+          const char* src = (c < a.nchunk0)
+              ? base0 + ((long)hy * a.Wh + hx) * a.pix_stride0 + c * 64 + q * 16
+              : base1 + ((long)hy * a.Wh + hx) * a.pix_stride1 + (c - a.nchunk0) * 64 + q * 16;
+          fr[f] = *(const u32x4_t*)src;
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < FB; ++f) {
+        const int u = u0 + f * NTH;
+        if (u < a_units && (u % NHPp) < NHP) *(u32x4_t*)(smem + (size_t)u * 16) = fr[f];
+      }
     }
+    // ---- this wave's K-slice of the fill: steps [s_lo, s_hi) of c_cnt*taps ----
     const int nsteps = c_cnt * taps;
-    const int ngroups = (nsteps + KG - 1) / KG;
-    const char* Bsrc = a.Bp + ((size_t)(c_begin * taps) * a.NTt + nt0) * 1024;
-    u32x4_t breg[BU];
-    // ---- weight group 0 ----
-    {
-      const int units = min(KG, nsteps) * NTWG * 64;
+    const int s_lo = (nsteps * wk) / WK, s_hi = (nsteps * (wk + 1)) / WK;
+    int cl = s_lo / taps;
+    int tap = s_lo - cl * taps;
+    int tyy = tap / k;
+    int txx = tap - tyy * k;
+    const char* Bs = Bwave + (size_t)(c_begin * taps + s_lo) * bstep;
+    u32x4_t bcur[NTW], bnext[NTW];
+    if (s_lo < s_hi) {
 #pragma unroll
-      for (int i = 0; i < BU; ++i) {
-        const int u = tid + i * NTH;
-        if (u < units) {
-          const int ks = u / (NTWG * 64), r = u - ks * (NTWG * 64);
-          breg[i] = *(const u32x4_t*)(Bsrc + (size_t)ks * a.NTt * 1024 + r * 16);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < BU; ++i) {
-        const int u = tid + i * NTH;
-        if (u < units) *(u32x4_t*)(Bbuf + (size_t)u * 16) = breg[i];
-      }
+      for (int j = 0; j < NTW; ++j) bcur[j] = *(const u32x4_t*)(Bs + j * 1024);
     }
-    __syncthreads();
-    for (int grp = 0; grp < ngroups; ++grp) {
-      const int s0 = grp * KG;
-      const bool more = grp + 1 < ngroups;
-      const int units_next = more ? min(KG, nsteps - (s0 + KG)) * NTWG * 64 : 0;
-      if (more) {
+    __syncthreads();                           // image visible to all waves
+    for (int s = s_lo; s < s_hi; ++s) {
+      if (s + 1 < s_hi) {
 #pragma unroll
-        for (int i = 0; i < BU; ++i) {
-          const int u = tid + i * NTH;
-          if (u < units_next) {
-            const int ks = u / (NTWG * 64), r = u - ks * (NTWG * 64);
-            breg[i] = *(const u32x4_t*)(Bsrc + (size_t)(s0 + KG + ks) * a.NTt * 1024 + r * 16);
-          }
-        }
+        for (int j = 0; j < NTW; ++j) bnext[j] = *(const u32x4_t*)(Bs + bstep + j * 1024);
       }
-      const char* Bcur = Bbuf + (grp & 1) * BG_BYTES;
-      const int nks = min(KG, nsteps - s0);
-      for (int ks = 0; ks < nks; ++ks) {
-        const int sl = s0 + ks;
-        const int cl = sl / taps;
-        const int tap = sl - cl * taps;
-        const int tyy = tap / k;
-        const int txx = tap - tyy * k;
-        const char* Ab = Abuf + ((size_t)(cl * NHP + (wm * MT + tyy) * HWt + txx)) * 64 + a_lane_off;
-        const char* Bb = Bcur + (size_t)(ks * NTWG + wn * NTW) * 1024 + lane * 16;
-        u32x4_t af[MT], bf[NTW];
+      const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
+      u32x4_t af[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + (size_t)i * HWt * 64);
+      for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + i * HWt * 16);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) bf[j] = *(const u32x4_t*)(Bb + j * 1024);
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(af[i], bcur[j], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) bcur[j] = bnext[j];
+      Bs += bstep;
+      if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+    }
+  }
+
+  // ------------------------------------------------------------------ K-slice reduction
+  if constexpr (WK > 1) {
+    // rounds r = 1..WK-1: the waves of slice r park their accumulators in LDS (tile-major, lane-linear),
+    // the slice-0 wave of the same column group adds them.
+    for (int r = 1; r < WK; ++r) {
+      __syncthreads();                         // LDS free (image reads / previous round done)
+      char* slot = smem + (size_t)wn * (MT * NTW * 1024) + lane * 16;
+      if (wk == r) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(af[i], bf[j], acc[i][j]);
-      }
-      if (more) {
-        char* Bnext = Bbuf + ((grp + 1) & 1) * BG_BYTES;
-#pragma unroll
-        for (int i = 0; i < BU; ++i) {
-          const int u = tid + i * NTH;
-          if (u < units_next) *(u32x4_t*)(Bnext + (size_t)u * 16) = breg[i];
-        }
+          for (int j = 0; j < NTW; ++j) *(f32x4_t*)(slot + (i * NTW + j) * 1024) = acc[i][j];
       }
       __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[i][j] += *(const f32x4_t*)(slot + (i * NTW + j) * 1024);
+      }
     }
+    if (wk != 0) return;
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -150,18 +158,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
   const int col = lane & 15;
   const int rbase = 4 * (lane >> 4);
   if constexpr (EPI == EPI_LSTM) {
-    typedef Elem<DT> E;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int y = y0 + wm * MT + i;
+    for (int cb = 0; cb < NTW / 4; ++cb) {
+      const int cblock = nt0 / 4 + cb;
+      const int ch = cblock * 16 + col;
+      const float bi = a.bias[(cblock * 4 + 0) * 16 + col];
+      const float bf_ = a.bias[(cblock * 4 + 1) * 16 + col];
+      const float bg = a.bias[(cblock * 4 + 2) * 16 + col];
+      const float bo = a.bias[(cblock * 4 + 3) * 16 + col];
 #pragma unroll
-      for (int cb = 0; cb < NTW / 4; ++cb) {
-        const int cblock = (nt0 + wn * NTW) / 4 + cb;
-        const int ch = cblock * 16 + col;
-        const float bi = a.bias[(cblock * 4 + 0) * 16 + col];
-        const float bf_ = a.bias[(cblock * 4 + 1) * 16 + col];
-        const float bg = a.bias[(cblock * 4 + 2) * 16 + col];
-        const float bo = a.bias[(cblock * 4 + 3) * 16 + col];
+      for (int i = 0; i < MT; ++i) {
+        const int y = y0 + i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int x = x0 + rbase + r;
@@ -191,10 +198,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
   } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int y = y0 + wm * MT + i;
+      const int y = y0 + i;
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        const int n = (nt0 + wn * NTW + j) * 16 + col;
+        const int n = (nt0 + j) * 16 + col;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int x = x0 + rbase + r;
@@ -214,30 +221,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
 }
 
 // ------------------------------------------------------------------------------ host side
-template <int DT, int EPI, int WM, int WN, int MT, int NTW>
+template <int DT, int EPI, int WN, int WK, int NTW>
 static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
-  constexpr int KG = (4 * WM + NTW - 1) / NTW;
-  constexpr int NTWG = WN * NTW;
-  constexpr int TH = WM * MT;
-  static_assert(TH == 8, "slab slack rows assume 8-row tiles");
-  const int NHP = (TH + 2 * a.p) * (16 + 2 * a.p);
+  const int NHP = (MT + 2 * a.p) * (16 + 2 * a.p);
+  a.nhp_pad = nint_round_up(NHP, 16);
+  const int chunk_bytes = 4 * a.nhp_pad * 16;
   const int nchunks = a.nchunk0 + a.nchunk1;
-  const int b_bytes = 2 * KG * NTWG * 1024;
-  // as many channel chunks per fill as fit in ~64 KiB (two workgroups per CU stay resident)
-  int cpf = (64 * 1024 - b_bytes) / (NHP * 64);
+  const int red_bytes = WK > 1 ? WN * MT * NTW * 1024 : 0;
+  // as many channel chunks per fill as fit in ~72 KiB (two workgroups per CU stay resident)
+  int cpf = (72 * 1024) / chunk_bytes;
   if (cpf < 1) cpf = 1;
   if (cpf > nchunks) cpf = nchunks;
+  // even out the fills (e.g. 5 chunks with room for 4 -> 3 + 2)
+  const int nfill = nint_cdiv(nchunks, cpf);
+  cpf = nint_cdiv(nchunks, nfill);
   a.cpf = cpf;
-  a.a_bytes = cpf * NHP * 64;
-  const size_t lds = (size_t)a.a_bytes + b_bytes;
+  a.a_bytes = cpf * chunk_bytes;
+  size_t lds = (size_t)a.a_bytes;
+  if ((size_t)red_bytes > lds) lds = red_bytes;
   if (lds > 160 * 1024) return NINT_E_LDS;
   a.tiles_x = nint_cdiv(a.W, 16);
-  a.tiles_y = nint_cdiv(a.H, TH);
-  auto kern = conv_igemm_kernel<DT, EPI, WM, WN, MT, NTW>;
-  if (lds > 64 * 1024) {
+  a.tiles_y = nint_cdiv(a.H, MT);
+  auto kern = conv_igemm_kernel<DT, EPI, WN, WK, NTW>;
+  if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  dim3 grid(a.tiles_x * a.tiles_y * N, ngroups_y), block(64 * WM * WN);
+  dim3 grid(a.tiles_x * a.tiles_y * N, ngroups_y), block(256);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
@@ -249,19 +257,19 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;
-    if (cbs % 4 == 0) return launch_cfg<DT, EPI, 1, 4, 8, 4>(a, N, cbs / 4, st);
-    if (cbs % 2 == 0) return launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st);
-    return launch_cfg<DT, EPI, 4, 1, 2, 4>(a, N, cbs, st);
+    if (cbs % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 4>(a, N, cbs / 4, st);
+    if (cbs % 2 == 0) return launch_cfg<DT, EPI, 2, 2, 4>(a, N, cbs / 2, st);
+    return launch_cfg<DT, EPI, 1, 4, 4>(a, N, cbs, st);
   } else {
-    // pick (WN, NTW) with WN*NTW dividing the tile count, widest first
-    if (ntiles % 16 == 0) return launch_cfg<DT, EPI, 1, 4, 8, 4>(a, N, ntiles / 16, st);
-    if (ntiles % 12 == 0) return launch_cfg<DT, EPI, 1, 4, 8, 3>(a, N, ntiles / 12, st);
-    if (ntiles % 8 == 0) return launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, ntiles / 8, st);
-    if (ntiles % 6 == 0) return launch_cfg<DT, EPI, 2, 2, 4, 3>(a, N, ntiles / 6, st);
-    if (ntiles % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 2, 4>(a, N, ntiles / 4, st);
-    if (ntiles % 3 == 0) return launch_cfg<DT, EPI, 4, 1, 2, 3>(a, N, ntiles / 3, st);
-    if (ntiles % 2 == 0) return launch_cfg<DT, EPI, 4, 1, 2, 2>(a, N, ntiles / 2, st);
-    return launch_cfg<DT, EPI, 4, 1, 2, 1>(a, N, ntiles, st);
+    // (WN, NTW) with WN*NTW dividing the tile count, widest first; leftover waves split K
+    if (ntiles % 16 == 0) return launch_cfg<DT, EPI, 4, 1, 4>(a, N, ntiles / 16, st);
+    if (ntiles % 12 == 0) return launch_cfg<DT, EPI, 4, 1, 3>(a, N, ntiles / 12, st);
+    if (ntiles % 8 == 0) return launch_cfg<DT, EPI, 2, 2, 4>(a, N, ntiles / 8, st);
+    if (ntiles % 6 == 0) return launch_cfg<DT, EPI, 2, 2, 3>(a, N, ntiles / 6, st);
+    if (ntiles % 4 == 0) return launch_cfg<DT, EPI, 1, 4, 4>(a, N, ntiles / 4, st);
+    if (ntiles % 3 == 0) return launch_cfg<DT, EPI, 1, 4, 3>(a, N, ntiles / 3, st);
+    if (ntiles % 2 == 0) return launch_cfg<DT, EPI, 1, 4, 2>(a, N, ntiles / 2, st);
+    return launch_cfg<DT, EPI, 1, 4, 1>(a, N, ntiles, st);
   }
 }
 

@@ -98,6 +98,7 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int cpf;               // channel chunks per LDS A fill
   int a_bytes;           // bytes reserved for the A image
+  int nhp_pad;           // halo-tile pixels rounded up to 16 (one g-plane of the A image)
   // LSTM epilogue
   const float* bias;     // [4*Ch16] permuted
   const float* c_prev;   // compact [N][H][W][Chp] or nullptr (= 0)

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at the bench workload's shapes (HIP events on the launch stream).
+    python tools/kbench.py [--dtype bf16] [--batch 8] [--iters 20] [--only fwd0,dgrad0,...]
+Prints one line per kernel: average ms, algorithmic TFLOP/s (or GB/s)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nasa_niswan_amd as pkg  # noqa: E402
+from nasa_niswan_amd.engine import LayerCfg, SeqEngine  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--T", type=int, default=12)
+    ap.add_argument("--C", type=int, default=62)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    lib = pkg.load_library()
+    hidden, ks = (64, 32, 16), (5, 3, 3)
+    cfgs, cin = [], args.C
+    for ch, k in zip(hidden, ks):
+        cfgs.append(LayerCfg(cin, ch, k)); cin = ch
+    eng = SeqEngine(cfgs, args.dtype, "cuda")
+    B, T, H, W = args.batch, args.T, 100, 154
+    ws = eng.acquire(B, T, H, W, True, False)
+    ws_w = [torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * 0.05 for c in cfgs]
+    ws_b = [torch.zeros(4 * c.Ch, device="cuda") for c in cfgs]
+    eng.pack_weights(ws_w, ws_b)
+    X = torch.randn(B, T, args.C, H, W, device="cuda")
+    eng.forward(ws, X)       # fills every slab with realistic (random-data) values
+    for l in range(3):
+        ws.dh[l].normal_(); ws.dc[l].normal_()
+    g, st = C.byref(ws.g), None
+    es = eng.es
+    halo_px, comp_px = ws.g.Hh * ws.g.Wh, H * W
+    only = set(args.only.split(",")) if args.only else None
+    rows = []
+
+    def run(name, fn, flops=None, bytes_=None):
+        if only and name not in only:
+            return
+        ms = timeit(fn, args.iters)
+        extra = f"{flops / ms / 1e9:8.1f} TFLOP/s" if flops else (f"{bytes_ / ms / 1e6:8.1f} GB/s" if bytes_ else "")
+        print(f"{name:12s} {ms * 1e3:9.1f} us  {extra}", flush=True)
+        rows.append((name, ms))
+
+    for l, cfg in enumerate(cfgs):
+        ly = eng.layers[l]
+        xs = ws.xs.data_ptr() + 1 * B * halo_px * ly.Cxp * es if l == 0 else ws.h[l - 1].data_ptr() + 2 * B * halo_px * ly.Cxp * es
+        hs = B * halo_px * ly.Chp * es
+        cs = B * comp_px * ly.Chp * 4
+        gs = B * comp_px * 4 * ly.Ch16 * es
+        dgs = B * halo_px * 4 * ly.Ch16 * es
+        fl = 2.0 * B * H * W * cfg.k ** 2 * (cfg.Cx + cfg.Ch) * 4 * cfg.Ch
+
+        def fwd(ly=ly, xs=xs, hs=hs, cs=cs, gs=gs, l=l):
+            assert lib.nint_cell_fwd(C.byref(ly), g, eng.dt, B, C.c_void_p(xs), C.c_void_p(ws.h[l].data_ptr() + hs),
+                                     C.c_void_p(ws.c[l].data_ptr() + cs), C.c_void_p(ws.h[l].data_ptr() + 2 * hs),
+                                     C.c_void_p(ws.c[l].data_ptr() + 2 * cs), C.c_void_p(ws.gates[l].data_ptr() + gs), st) == 0
+        run(f"fwd{l}", fwd, fl)
+
+        def pw(ly=ly, cs=cs, gs=gs, dgs=dgs, l=l):
+            assert lib.nint_cell_bwd_pointwise(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.gates[l].data_ptr() + gs),
+                                               C.c_void_p(ws.c[l].data_ptr() + cs), C.c_void_p(ws.c[l].data_ptr() + 2 * cs),
+                                               C.c_void_p(ws.dh[l].data_ptr()), C.c_void_p(ws.dc[l].data_ptr()),
+                                               C.c_void_p(ws.dG[l].data_ptr() + dgs), st) == 0
+        run(f"pointwise{l}", pw, None, B * comp_px * ly.Ch16 * (8 * es + 24))
+    # fill dG for every t so that wgrad sees random data
+    for l in range(3):
+        ws.dG[l].view(torch.bfloat16 if es == 2 else torch.float32).normal_(std=0.05)
+    for l, cfg in enumerate(cfgs):
+        ly = eng.layers[l]
+        dgs = B * halo_px * 4 * ly.Ch16 * es
+        dx = ws.dh[l - 1].data_ptr() if l > 0 else None
+        ncols = cfg.Ch + (cfg.Cx if l > 0 else 0)
+        fl = 2.0 * B * H * W * cfg.k ** 2 * 4 * cfg.Ch * ncols
+
+        def dg(ly=ly, dgs=dgs, dx=dx, l=l):
+            assert lib.nint_conv_dgrad(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.dG[l].data_ptr() + dgs),
+                                       C.c_void_p(dx) if dx else None, C.c_void_p(ws.dh[l].data_ptr()), st) == 0
+        run(f"dgrad{l}", dg, fl)
+        dW = torch.empty(4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k, device="cuda")
+        db = torch.empty(4 * cfg.Ch, device="cuda")
+        x_all = ws.xs.data_ptr() if l == 0 else ws.h[l - 1].data_ptr() + B * halo_px * ly.Cxp * es
+        flw = 2.0 * T * B * H * W * cfg.k ** 2 * (cfg.Cx + cfg.Ch) * 4 * cfg.Ch
+
+        def wg(ly=ly, x_all=x_all, dW=dW, db=db, l=l):
+            assert lib.nint_conv_wgrad(C.byref(ly), g, eng.dt, T * B, C.c_void_p(ws.dG[l].data_ptr()), C.c_void_p(x_all),
+                                       C.c_void_p(ws.h[l].data_ptr()), C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()),
+                                       C.c_void_p(eng.wg_partial.data_ptr()), eng.wg_partial.numel() * 4, eng.n_cu, st) == 0
+        run(f"wgrad{l}", wg, flw)
+    xs_pack = lambda: lib.nint_pack_btchw(C.c_void_p(X.data_ptr()), C.c_void_p(ws.xs.data_ptr()), B, T, args.C, ws.Cxp0, g, eng.dt, st)
+    run("pack", xs_pack, None, X.numel() * 4 + B * T * comp_px * ws.Cxp0 * es)
+    tot = sum(ms * (T if not n.startswith(("wgrad", "pack")) else 1) for n, ms in rows)
+    print(f"sum over a step (T x per-step kernels + wgrad + pack): {tot:.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
