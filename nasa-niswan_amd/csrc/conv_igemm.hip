@@ -24,6 +24,10 @@
 enum { EPI_LSTM = 0, EPI_DGRAD = 1 };
 
 constexpr int MT = 8;   // row tiles per wave = rows of the pixel tile
+#ifndef NINT_BD
+#define NINT_BD 3
+#endif
+constexpr int BD = NINT_BD;   // depth of the per-wave weight-fragment ring
 
 template <int DT, int EPI, int WN, int WK, int NTW>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
@@ -103,29 +107,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     int tyy = tap / k;
     int txx = tap - tyy * k;
     const char* Bs = Bwave + (size_t)(c_begin * taps + s_lo) * bstep;
-    u32x4_t bcur[NTW], bnext[NTW];
+    // B ring: BD K-steps of weight fragments in flight per wave (L2 latency under load is several
+    // K-steps long and only two waves share a SIMD, so one step of prefetch is not enough)
+    // The ring loop is kept BRANCH-FREE (reloads are unconditional, their address is clamped to the
+    // slice's last step) so that the compiler can count outstanding loads and emits
+    // s_waitcnt vmcnt((BD-1)*NTW) instead of draining the ring with vmcnt(0) at every step.
+    u32x4_t bq[BD][NTW];
+    const char* Blast = Bs + (size_t)(s_hi - 1 - s_lo) * bstep;     // last step of this slice
+    const char* Bn = Bs;                                            // next step to load
     if (s_lo < s_hi) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bcur[j] = *(const u32x4_t*)(Bs + j * 1024);
+      for (int d = 0; d < BD; ++d) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
+        Bn = (Bn < Blast) ? Bn + bstep : Blast;
+      }
     }
     __syncthreads();                           // image visible to all waves
-    for (int s = s_lo; s < s_hi; ++s) {
-      if (s + 1 < s_hi) {
+    int s = s_lo;
+    for (; s + BD <= s_hi; s += BD) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) bnext[j] = *(const u32x4_t*)(Bs + bstep + j * 1024);
+      for (int d = 0; d < BD; ++d) {
+        const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
+        u32x4_t af[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + i * HWt * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(af[i], bq[d][j], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
+        Bn = (Bn < Blast) ? Bn + bstep : Blast;
+        if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
       }
-      const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
-      u32x4_t af[MT];
+    }
+    // remainder (< BD steps): ring slots 0.. already hold exactly these steps
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + i * HWt * 16);
+    for (int d = 0; d < BD - 1; ++d) {
+      if (s + d < s_hi) {
+        const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
+        u32x4_t af[MT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + i * HWt * 16);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(af[i], bcur[j], acc[i][j]);
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bcur[j] = bnext[j];
-      Bs += bstep;
-      if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(af[i], bq[d][j], acc[i][j]);
+        if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+      }
     }
   }
 
