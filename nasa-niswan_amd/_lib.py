@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnint_hip.so")
+LIB_PATH = os.environ.get("NINT_LIB", os.path.join(HERE, "libnint_hip.so"))   # NINT_LIB: experiment builds
 
 NINT_F32, NINT_BF16 = 0, 1
 NINT_MAX_LAYERS = 8

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(af[i], bq[d][j], acc[i][j]);
+          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
         Bn = (Bn < Blast) ? Bn + bstep : Blast;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(af[i], bq[d][j], acc[i][j]);
+          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
         if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
       }
     }
@@ -184,43 +184,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 
   // ------------------------------------------------------------------ epilogue
-  // C/D map of the 16x16 MFMA: column = lane&15, row = 4*(lane>>4) + reg.
-  const int col = lane & 15;
-  const int rbase = 4 * (lane >> 4);
+  // Operands are fed SWAPPED to the MFMA (A := weight fragment, B := pixel fragment), so the
+  // 16x16 result tile is D[channel][pixel]: column = lane&15 = pixel, row = 4*(lane>>4)+reg =
+  // channel.  A lane therefore owns 4 CONSECUTIVE channels of one pixel and every epilogue
+  // access is a 16-byte (f32) / 8-byte (bf16) vector on channels-last memory.
+  const int px = lane & 15;
+  const int c4 = 4 * (lane >> 4);
+  const int x = x0 + px;
   if constexpr (EPI == EPI_LSTM) {
 #pragma unroll
     for (int cb = 0; cb < NTW / 4; ++cb) {
       const int cblock = nt0 / 4 + cb;
-      const int ch = cblock * 16 + col;
-      const float bi = a.bias[(cblock * 4 + 0) * 16 + col];
-      const float bf_ = a.bias[(cblock * 4 + 1) * 16 + col];
-      const float bg = a.bias[(cblock * 4 + 2) * 16 + col];
-      const float bo = a.bias[(cblock * 4 + 3) * 16 + col];
+      const int ch = cblock * 16 + c4;
+      const f32x4_t bi = *(const f32x4_t*)(a.bias + (cblock * 4 + 0) * 16 + c4);
+      const f32x4_t bf_ = *(const f32x4_t*)(a.bias + (cblock * 4 + 1) * 16 + c4);
+      const f32x4_t bg = *(const f32x4_t*)(a.bias + (cblock * 4 + 2) * 16 + c4);
+      const f32x4_t bo = *(const f32x4_t*)(a.bias + (cblock * 4 + 3) * 16 + c4);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int y = y0 + i;
+        if (y < a.H && x < a.W) {
+          const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+          f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
+          if (a.c_prev) cp = *(const f32x4_t*)(a.c_prev + pix * a.Chp + ch);
+          f32x4_t gi, gf, gg, go, cn, hn;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int x = x0 + rbase + r;
-          if (y < a.H && x < a.W) {
-            const float gi = sigmoidf_(acc[i][cb * 4 + 0][r] + bi);
-            const float gf = sigmoidf_(acc[i][cb * 4 + 1][r] + bf_);
-            const float gg = tanhf_(acc[i][cb * 4 + 2][r] + bg);
-            const float go = sigmoidf_(acc[i][cb * 4 + 3][r] + bo);
-            const size_t pix = ((size_t)img * a.H + y) * a.W + x;
-            const float cp = a.c_prev ? a.c_prev[pix * a.Chp + ch] : 0.f;
-            const float cn = cp * gf + gi * gg;          // model.py:228
-            const float hn = go * tanhf_(cn);            // model.py:229
-            a.c_out[pix * a.Chp + ch] = cn;
-            const size_t hpix = ((size_t)img * a.Hh + (y + a.P)) * a.Wh + (x + a.P);
-            store_elem<DT>(a.h_out, hpix * a.Chp + ch, hn);
-            if (a.gates_out) {
-              const size_t gb = pix * (size_t)(4 * a.Ch16) + (size_t)cblock * 64 + col;
-              store_elem<DT>(a.gates_out, gb + 0, gi);
-              store_elem<DT>(a.gates_out, gb + 16, gf);
-              store_elem<DT>(a.gates_out, gb + 32, gg);
-              store_elem<DT>(a.gates_out, gb + 48, go);
-            }
+          for (int r = 0; r < 4; ++r) {
+            gi[r] = sigmoidf_(acc[i][cb * 4 + 0][r] + bi[r]);
+            gf[r] = sigmoidf_(acc[i][cb * 4 + 1][r] + bf_[r]);
+            gg[r] = tanhf_(acc[i][cb * 4 + 2][r] + bg[r]);
+            go[r] = sigmoidf_(acc[i][cb * 4 + 3][r] + bo[r]);
+            cn[r] = cp[r] * gf[r] + gi[r] * gg[r];       // model.py:228
+            hn[r] = go[r] * tanhf_(cn[r]);               // model.py:229
+          }
+          *(f32x4_t*)(a.c_out + pix * a.Chp + ch) = cn;
+          const size_t hpix = ((size_t)img * a.Hh + (y + a.P)) * a.Wh + (x + a.P);
+          store_vec4<DT>(a.h_out, hpix * a.Chp + ch, hn);
+          if (a.gates_out) {
+            const size_t gb = pix * (size_t)(4 * a.Ch16) + (size_t)cblock * 64 + c4;
+            store_vec4<DT>(a.gates_out, gb + 0, gi);
+            store_vec4<DT>(a.gates_out, gb + 16, gf);
+            store_vec4<DT>(a.gates_out, gb + 32, gg);
+            store_vec4<DT>(a.gates_out, gb + 48, go);
           }
         }
       }
@@ -229,20 +234,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int y = y0 + i;
+      if (y < a.H && x < a.W) {
+        const size_t pix = ((size_t)img * a.H + y) * a.W + x;
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int n = (nt0 + j) * 16 + col;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int x = x0 + rbase + r;
-          if (y < a.H && x < a.W) {
-            const size_t pix = ((size_t)img * a.H + y) * a.W + x;
-            const float v = acc[i][j][r];
-            if (n < a.C0p) {
-              if (a.out0) a.out0[pix * a.C0p + n] += v;
-            } else if (a.out1) {
-              a.out1[pix * a.C1p + (n - a.C0p)] = v;
+        for (int j = 0; j < NTW; ++j) {
+          const int n = (nt0 + j) * 16 + c4;
+          if (n < a.C0p) {
+            if (a.out0) {
+              f32x4_t* d = (f32x4_t*)(a.out0 + pix * a.C0p + n);
+              *d = *d + acc[i][j];
             }
+          } else if (a.out1) {
+            *(f32x4_t*)(a.out1 + pix * a.C1p + (n - a.C0p)) = acc[i][j];
           }
         }
       }

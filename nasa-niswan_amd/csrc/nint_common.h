@@ -57,6 +57,18 @@ template <int DT> __device__ __forceinline__ void store_elem(void* p, size_t i, 
 template <> __device__ __forceinline__ void store_elem<NINT_F32>(void* p, size_t i, float v) { ((float*)p)[i] = v; }
 template <> __device__ __forceinline__ void store_elem<NINT_BF16>(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
 
+// 4 consecutive elements (16-byte f32 / 8-byte bf16 vector store); i must be a multiple of 4
+template <int DT> __device__ __forceinline__ void store_vec4(void* p, size_t i, f32x4_t v);
+template <> __device__ __forceinline__ void store_vec4<NINT_F32>(void* p, size_t i, f32x4_t v) {
+  *(f32x4_t*)((float*)p + i) = v;
+}
+template <> __device__ __forceinline__ void store_vec4<NINT_BF16>(void* p, size_t i, f32x4_t v) {
+  u32x2_t w;
+  w[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  w[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  *(u32x2_t*)((uint16_t*)p + i) = w;
+}
+
 // One K-step of D += A*B on a 16x16 tile from two 16-byte fragments.
 //   bf16: lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], j=0..7
 //   f32 : four MFMAs; in MFMA j lane l supplies A[row l&15][k = l>>4] = element j of its fragment,
