@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 100
+#define NINT_VERSION 101
+#define NINT_DB_ROWS 1024   /* rows of bias-gradient partials one fused pointwise-backward launch writes */
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
 
@@ -85,7 +86,8 @@ typedef struct nint_seq {
   float* dx;                           /* f32 compact [T*B][H][W][Cxp0] (need_dx only) */
   float* dW[NINT_MAX_LAYERS];          /* f32 OIHW (4Ch, Cx+Ch, k, k) gradient, overwritten */
   float* db[NINT_MAX_LAYERS];          /* f32 (4Ch) gradient, overwritten */
-  float* wg_partial;                   /* f32 split-K slabs for wgrad (size from nint_seq_workspace_sizes) */
+  float* db_partial[NINT_MAX_LAYERS];  /* f32 [T][NINT_DB_ROWS][4*Ch16] bias-gradient partial rows (may be NULL) */
+  float* wg_partial;                   /* f32 split-K slabs for wgrad (size from nint_wgrad_workspace_bytes) */
   size_t wg_partial_bytes;
 } nint_seq;
 
@@ -134,7 +136,9 @@ int nint_cell_fwd(const nint_layer* ly /*host*/, const nint_geom* g /*host*/, in
  * the stashed gates and c_prev / c_new; writes pre-activation gate grads into the dG halo slab. */
 int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                             const void* gates, const float* c_prev, const float* c_new,
-                            const float* dh, float* dc, void* dG, void* stream);
+                            const float* dh, float* dc, void* dG, float* db_partial, void* stream);
+/* db_partial (may be NULL): f32 [NINT_DB_ROWS][4*Ch16], one row of bias-gradient partial sums per
+ * workgroup of this launch (fused column sum of dG; needs 256 % (Ch16/4) == 0, else NINT_E_SHAPE). */
 
 /* conv backward-data of model.py:220: d cat[x,h] = W^T (*) dG.  h columns are STORED to dh_prev,
  * x columns are ACCUMULATED (+=) into dx_accum (the layer below's dh, or dx); either may be NULL. */
@@ -147,7 +151,10 @@ int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
 size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, int n_cu);
 int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                     const void* dG, const void* x_slab, const void* h_slab,
-                    float* dW, float* db, float* partial, size_t partial_bytes, int n_cu, void* stream);
+                    float* dW, float* db, float* partial, size_t partial_bytes, int n_cu,
+                    const float* db_partial, int db_rows, void* stream);
+/* db_partial/db_rows: the rows written by the fused pointwise-backward launches of all time steps
+ * (db = their column sum); NULL -> db is computed by a column-sum pass over dG instead. */
 
 /* ---- whole-sequence drivers (model.py:253-274 and its BPTT), all launches from C++ ---------- */
 int nint_seq_fwd(const nint_seq* s /*host*/, void* stream);

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("NINT_LIB", os.path.join(HERE, "libnint_hip.so"))   # 
 NINT_F32, NINT_BF16 = 0, 1
 NINT_MAX_LAYERS = 8
 NINT_LOSS_SCRATCH_FLOATS = 2050
+NINT_DB_ROWS = 1024
 
 vp = C.c_void_p
 
@@ -34,7 +35,7 @@ class NintSeq(C.Structure):
                 ("xs", vp), ("h", vp * NINT_MAX_LAYERS), ("c", vp * NINT_MAX_LAYERS),
                 ("gates", vp * NINT_MAX_LAYERS), ("dG", vp * NINT_MAX_LAYERS), ("dh", vp * NINT_MAX_LAYERS),
                 ("dc", vp * NINT_MAX_LAYERS), ("dx", vp), ("dW", vp * NINT_MAX_LAYERS), ("db", vp * NINT_MAX_LAYERS),
-                ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t)]
+                ("db_partial", vp * NINT_MAX_LAYERS), ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t)]
 
 
 # every symbol include/nint.h declares: name -> (restype, argtypes)
@@ -54,10 +55,10 @@ SIGNATURES = {
     "nint_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "nint_pack_weights": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, vp]),
     "nint_cell_fwd": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
-    "nint_cell_bwd_pointwise": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
+    "nint_cell_bwd_pointwise": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nint_conv_dgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp]),
     "nint_wgrad_workspace_bytes": (_SZ, [_PL, _I, _I]),
-    "nint_conv_wgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, _SZ, _I, vp]),
+    "nint_conv_wgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, _SZ, _I, vp, _I, vp]),
     "nint_seq_fwd": (_I, [_PS, vp]),
     "nint_seq_bwd": (_I, [_PS, vp]),
     "nint_head_fwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, _PG, _I, vp]),
@@ -88,7 +89,7 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nint_version() != 100:
+    if lib.nint_version() != 101:
         raise NintError("libnint_hip.so version mismatch")
     _lib = lib
     return lib

@@ -217,53 +217,103 @@ extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, vo
 //   dGi = di*i*(1-i), dGf = df*f*(1-f), dGg = dg*(1-g^2), dGo = do*o*(1-o)
 // Reads the gate stash (ET), c_prev / c_new / dh / dc (f32); writes dG into its halo slab (ET,
 // interior only) and dc_prev in place.  One thread per (pixel, channel), channel fastest.
-template <int DT>
-__global__ void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
+// 4 consecutive elements as f32 (16-byte f32 / 8-byte bf16 vector load); i must be a multiple of 4
+template <int DT> __device__ __forceinline__ f32x4_t load_vec4(const void* p, size_t i);
+template <> __device__ __forceinline__ f32x4_t load_vec4<NINT_F32>(const void* p, size_t i) { return *(const f32x4_t*)((const float*)p + i); }
+template <> __device__ __forceinline__ f32x4_t load_vec4<NINT_BF16>(const void* p, size_t i) {
+  const u32x2_t w = *(const u32x2_t*)((const uint16_t*)p + i);
+  return (f32x4_t){bf2f((uint16_t)(w[0] & 0xffff)), bf2f((uint16_t)(w[0] >> 16)), bf2f((uint16_t)(w[1] & 0xffff)), bf2f((uint16_t)(w[1] >> 16))};
+}
+
+// One thread per (pixel, 4 consecutive hidden channels): every access is a 16-byte (f32) or 8-byte
+// (bf16) vector.  With FUSE_DB each thread keeps the SAME channel quad over its grid-stride loop
+// (256 % (Ch16/4) == 0), accumulates the 16 bias-gradient partial sums in registers and the block
+// writes one row of db_partial[gridDim.x][4*Ch16] -- fixed order, no atomics; the rows are folded
+// by nint_conv_wgrad.  This replaces a separate full pass over dG.
+template <int DT, bool FUSE_DB>
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
                                           const float* __restrict__ c_new, const float* __restrict__ dh,
-                                          float* __restrict__ dc, void* __restrict__ dG, int N, int H, int W, int P,
-                                          int Hh, int Wh, int Ch16, int Chp) {
-  const size_t total = (size_t)N * H * W * Ch16;
+                                          float* __restrict__ dc, void* __restrict__ dG, float* __restrict__ db_partial,
+                                          int N, int H, int W, int P, int Hh, int Wh, int Ch16, int Chp) {
+  const int nq = Ch16 >> 2;
+  const size_t total = (size_t)N * H * W * nq;
   const int Gc = 4 * Ch16;
+  f32x4_t s_i = {0.f, 0.f, 0.f, 0.f}, s_f = s_i, s_g = s_i, s_o = s_i;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ch = i % Ch16;
-    const size_t pix = i / Ch16;
+    const int q = i % nq;
+    const size_t pix = i / nq;
     const int x = pix % W;
     size_t r = pix / W;
     const int y = r % H;
     const int n = r / H;
+    const int ch = 4 * q;
     const int cblock = ch >> 4, col = ch & 15;
     const size_t gb = pix * Gc + (size_t)cblock * 64 + col;
-    const float gi = load_elem<DT>(gates, gb);
-    const float gf = load_elem<DT>(gates, gb + 16);
-    const float gg = load_elem<DT>(gates, gb + 32);
-    const float go = load_elem<DT>(gates, gb + 48);
+    const f32x4_t gi = load_vec4<DT>(gates, gb);
+    const f32x4_t gf = load_vec4<DT>(gates, gb + 16);
+    const f32x4_t gg = load_vec4<DT>(gates, gb + 32);
+    const f32x4_t go = load_vec4<DT>(gates, gb + 48);
     const size_t ci = pix * Chp + ch;
-    const float cp = c_prev ? c_prev[ci] : 0.f;
-    const float tc = tanhf_(c_new[ci]);
-    const float dhv = dh[ci];
-    const float dct = dc[ci] + dhv * go * (1.f - tc * tc);
-    const float d_o = dhv * tc;
+    f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
+    if (c_prev) cp = *(const f32x4_t*)(c_prev + ci);
+    const f32x4_t cn = *(const f32x4_t*)(c_new + ci);
+    const f32x4_t dhv = *(const f32x4_t*)(dh + ci);
+    const f32x4_t dcv = *(const f32x4_t*)(dc + ci);
+    f32x4_t o_i, o_f, o_g, o_o, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float tc = tanhf_(cn[e]);
+      const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
+      const float d_o = dhv[e] * tc;
+      o_i[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+      o_f[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+      o_g[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+      o_o[e] = d_o * go[e] * (1.f - go[e]);
+      dcp[e] = dct * gf[e];
+    }
     const size_t ob = ((((size_t)n * Hh) + (y + P)) * Wh + (x + P)) * Gc + (size_t)cblock * 64 + col;
-    store_elem<DT>(dG, ob, dct * gg * gi * (1.f - gi));
-    store_elem<DT>(dG, ob + 16, dct * cp * gf * (1.f - gf));
-    store_elem<DT>(dG, ob + 32, dct * gi * (1.f - gg * gg));
-    store_elem<DT>(dG, ob + 48, d_o * go * (1.f - go));
-    dc[ci] = dct * gf;
+    store_vec4<DT>(dG, ob, o_i);
+    store_vec4<DT>(dG, ob + 16, o_f);
+    store_vec4<DT>(dG, ob + 32, o_g);
+    store_vec4<DT>(dG, ob + 48, o_o);
+    *(f32x4_t*)(dc + ci) = dcp;
+    if constexpr (FUSE_DB) { s_i += o_i; s_f += o_f; s_g += o_g; s_o += o_o; }
+  }
+  if constexpr (FUSE_DB) {
+    __shared__ float red[16][256 + 4];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0 + e][t] = s_i[e]; red[4 + e][t] = s_f[e]; red[8 + e][t] = s_g[e]; red[12 + e][t] = s_o[e];
+    }
+    __syncthreads();
+    const int groups = 256 / nq;
+    for (int o = t; o < Gc; o += 256) {
+      const int v = o / nq, q = o % nq;          // v = gate*4 + e
+      float acc = 0.f;
+      for (int g = 0; g < groups; ++g) acc += red[v][g * nq + q];
+      const int gate = v >> 2, ch = 4 * q + (v & 3);
+      db_partial[(size_t)blockIdx.x * Gc + (ch >> 4) * 64 + gate * 16 + (ch & 15)] = acc;
+    }
   }
 }
 
 extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                        const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
-                                       void* stream) {
+                                       float* db_partial, void* stream) {
   if (!ly || !g || !gates || !c_new || !dh || !dc || !dG || N <= 0) return NINT_E_ARG;
-  const size_t total = (size_t)N * g->H * g->W * ly->Ch16;
+  if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
+  const int nq = ly->Ch16 / 4;
+  if (db_partial && 256 % nq != 0) return NINT_E_SHAPE;     // caller falls back to the column-sum pass
+  const size_t total = (size_t)N * g->H * g->W * nq;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == NINT_BF16)
-    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp);
-  else if (dtype == NINT_F32)
-    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp);
-  else
-    return NINT_E_ARG;
+  // a fused launch always has exactly NINT_DB_ROWS blocks (idle blocks write zero rows)
+  const dim3 grid = db_partial ? dim3(NINT_DB_ROWS) : grid1d(total);
+#define NINT_PW(DT_, F_) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<DT_, F_>), grid, dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, \
+                                            db_partial, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp)
+  if (dtype == NINT_BF16) { if (db_partial) NINT_PW(NINT_BF16, true); else NINT_PW(NINT_BF16, false); }
+  else { if (db_partial) NINT_PW(NINT_F32, true); else NINT_PW(NINT_F32, false); }
+#undef NINT_PW
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }

@@ -150,8 +150,11 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       const char* gates = (const char*)s->gates[l] + (size_t)t * B * comp_px * Gc * es;
       char* dG = (char*)s->dG[l] + (size_t)t * B * halo_px * Gc * es;
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
+      // bias-gradient partial rows of this (t, l): fused into the pointwise pass when the shape allows
+      float* dbp = (s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0)
+                       ? s->db_partial[l] + (size_t)t * NINT_DB_ROWS * Gc : nullptr;
       rc = nint_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
-                                   s->dh[l], s->dc[l], dG, stream);
+                                   s->dh[l], s->dc[l], dG, dbp, stream);
       if (rc != NINT_OK) return rc;
       float* dx_accum = (l > 0) ? s->dh[l - 1]
                                 : (s->need_dx ? s->dx + (size_t)t * B * comp_px * ly->Cxp : nullptr);
@@ -166,8 +169,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     const nint_layer* ly = &s->layer[l];
     const char* x_all = (l == 0) ? (const char*)s->xs
                                  : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
+    const bool fused_db = s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0;
     rc = nint_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
-                         s->wg_partial, s->wg_partial_bytes, s->n_cu, stream);
+                         s->wg_partial, s->wg_partial_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
+                         s->T * NINT_DB_ROWS, stream);
     if (rc != NINT_OK) return rc;
   }
   return NINT_OK;

@@ -206,35 +206,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// Fold the split-K slabs into dW (OIHW f32).  One thread per weight element; fixed split order.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ px, const float* __restrict__ ph, float* __restrict__ dW,
-                                    int Cx, int Ch, int k, int NB, int CBx, int CBh, int NTC, int splits_x,
-                                    int splits_h) {
+// Fold the split-K slabs of ONE source (x or h part) into dW (OIHW f32).  One thread per element of
+// the slab layout [block][j][n'loc 64][c 16] -> every split is read fully coalesced, in fixed order
+// (bitwise reproducible); only the single write per weight is scattered.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Cx, int Ch, int Ch16, int k,
+                                    int NB, int CB, int NTC, int splits, int is_h) {
   const int taps = k * k, Ctot = Cx + Ch;
-  const size_t total = (size_t)4 * Ch * Ctot * taps;
-  const int J = taps * NTC, CW = 16 * NTC;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int tap = i % taps;
-    size_t r = i / taps;
-    const int ic = r % Ctot;
-    const int o = r / Ctot;
-    const int gate = o / Ch, ch = o % Ch;
-    const int np = (ch >> 4) * 64 + gate * 16 + (ch & 15);
-    const int nb = np >> 6, nloc = np & 63;
-    const bool isx = ic < Cx;
-    const int cc = isx ? ic : ic - Cx;
-    const int cb = cc / CW, ct = (cc % CW) >> 4, c16 = cc & 15;
-    const int CB = isx ? CBx : CBh;
-    const int splits = isx ? splits_x : splits_h;
-    const float* part = isx ? px : ph;
-    const int j = tap * NTC + ct;
-    const size_t blk = (size_t)(nb * CB + cb);
-    const size_t stride = (size_t)NB * CB * J * 1024;
-    const size_t off = (blk * J + j) * 1024 + nloc * 16 + c16;
+  const int J = taps * NTC;
+  const size_t slab = (size_t)NB * CB * J * 1024;
+  const int Csrc = is_h ? Ch : Cx;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < slab; i += (size_t)gridDim.x * blockDim.x) {
+    const int c16 = i & 15, nloc = (i >> 4) & 63;
+    size_t r = i >> 10;
+    const int j = r % J; r /= J;
+    const int cb = r % CB;
+    const int nb = r / CB;
+    const int tap = j / NTC, ct = j - tap * NTC;
+    const int cc = (cb * NTC + ct) * 16 + c16;          // channel inside this source
+    const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
+    const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
+    if (cc >= Csrc || ch >= Ch) continue;               // padding rows / columns
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += part[sp * stride + off];
-    dW[i] = s;
+    for (int sp = 0; sp < splits; ++sp) s += part[sp * slab + i];
+    const int ic = is_h ? Cx + cc : cc;
+    dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
   }
+}
+
+// column sums of a row-major f32 matrix [rows][Gc]: grid = (row splits, Gc/64); fixed order.
+__global__ __launch_bounds__(256) void rowsum_partial_kernel(const float* __restrict__ m, float* __restrict__ partial, int rows, int Gc) {
+  const int colgrp = blockIdx.y, col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int r = blockIdx.x * 4 + sub; r < rows; r += gridDim.x * 4) acc += m[(size_t)r * Gc + colgrp * 64 + col];
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sub == 0) partial[((size_t)blockIdx.x * gridDim.y + colgrp) * 64 + col] = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
 }
 
 // db[o] = sum over all pixels of dG[.,o]: grid = (row splits, column groups of 64); fixed order.
@@ -292,8 +299,10 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   pl->ntiles = g ? N * pl->tiles_x * pl->tiles_y : (1 << 30);
   if (n_cu <= 0) n_cu = 256;
   auto splits_for = [&](int CB) {
-    int s = nint_cdiv(3 * n_cu, pl->NB * CB);
-    if (s > pl->ntiles) s = pl->ntiles;
+    // two workgroups per CU in flight, but never fewer than 32 pixel tiles per split: the
+    // accumulator flush (J KiB-tiles per workgroup) must stay small against the K work
+    int s = nint_cdiv(2 * n_cu, pl->NB * CB);
+    if (s > pl->ntiles / 32) s = pl->ntiles / 32;
     if (s < 1) s = 1;
     return s;
   };
@@ -306,7 +315,7 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   pl->splits_h = nint_cdiv(pl->ntiles, pl->tps_h);
   const size_t fx = (size_t)pl->splits_x * pl->NB * pl->CBx * pl->J * 1024;
   const size_t fh = (size_t)pl->splits_h * pl->NB * pl->CBh * pl->J * 1024;
-  pl->db_rows = 2 * n_cu;
+  pl->db_rows = 64;
   pl->off_h = fx;
   pl->off_db = fx + fh;
   pl->total_floats = fx + fh + (size_t)pl->db_rows * 4 * ly->Ch16;
@@ -341,7 +350,7 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
 
 extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG,
                                const void* x_slab, const void* h_slab, float* dW, float* db, float* partial,
-                               size_t partial_bytes, int n_cu, void* stream) {
+                               size_t partial_bytes, int n_cu, const float* db_partial, int db_rows, void* stream) {
   if (!ly || !g || !dG || !x_slab || !h_slab || !dW || !db || !partial || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   WgPlan pl;
@@ -375,21 +384,25 @@ extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dty
       rc = pl.JW == 5 ? launch_wgrad<NINT_F32, 5>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 7>(a, splits, nblk, st);
     if (rc != NINT_OK) return rc;
   }
-  {
-    const size_t total = (size_t)4 * ly->Ch * (ly->Cx + ly->Ch) * ly->k * ly->k;
-    size_t gsz = (total + 255) / 256;
-    if (gsz > 8192) gsz = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, st, partial, partial + pl.off_h, dW,
-                       ly->Cx, ly->Ch, ly->k, pl.NB, pl.CBx, pl.CBh, pl.NTC, pl.splits_x, pl.splits_h);
+  for (int part = 0; part < 2; ++part) {
+    const int CB = part == 0 ? pl.CBx : pl.CBh;
+    const size_t slab = (size_t)pl.NB * CB * pl.J * 1024;
+    size_t gsz = (slab + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, st, partial + (part == 0 ? 0 : pl.off_h), dW,
+                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, part == 0 ? pl.splits_x : pl.splits_h, part);
     NINT_LAUNCH_CHECK();
   }
   {
     float* dbp = partial + pl.off_db;
     dim3 grid(pl.db_rows, Gc / 64);
-    if (dtype == NINT_BF16)
+    if (db_partial) {
+      hipLaunchKernelGGL(rowsum_partial_kernel, grid, dim3(256), 0, st, db_partial, dbp, db_rows, Gc);
+    } else if (dtype == NINT_BF16) {
       hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
-    else
+    } else {
       hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+    }
     NINT_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(nint_cdiv(4 * ly->Ch, 256)), dim3(256), 0, st, dbp, db, ly->Ch, Gc, pl.db_rows);
     NINT_LAUNCH_CHECK();

@@ -81,7 +81,7 @@ def main():
             assert lib.nint_cell_bwd_pointwise(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.gates[l].data_ptr() + gs),
                                                C.c_void_p(ws.c[l].data_ptr() + cs), C.c_void_p(ws.c[l].data_ptr() + 2 * cs),
                                                C.c_void_p(ws.dh[l].data_ptr()), C.c_void_p(ws.dc[l].data_ptr()),
-                                               C.c_void_p(ws.dG[l].data_ptr() + dgs), st) == 0
+                                               C.c_void_p(ws.dG[l].data_ptr() + dgs), C.c_void_p(ws.dbp[l].data_ptr()), st) == 0
         run(f"pointwise{l}", pw, None, B * comp_px * ly.Ch16 * (8 * es + 24))
     # fill dG for every t so that wgrad sees random data
     for l in range(3):
@@ -105,7 +105,8 @@ def main():
         def wg(ly=ly, x_all=x_all, dW=dW, db=db, l=l):
             assert lib.nint_conv_wgrad(C.byref(ly), g, eng.dt, T * B, C.c_void_p(ws.dG[l].data_ptr()), C.c_void_p(x_all),
                                        C.c_void_p(ws.h[l].data_ptr()), C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()),
-                                       C.c_void_p(eng.wg_partial.data_ptr()), eng.wg_partial.numel() * 4, eng.n_cu, st) == 0
+                                       C.c_void_p(eng.wg_partial.data_ptr()), eng.wg_partial.numel() * 4, eng.n_cu,
+                                       C.c_void_p(ws.dbp[l].data_ptr()), T * 1024, st) == 0
         run(f"wgrad{l}", wg, flw)
     xs_pack = lambda: lib.nint_pack_btchw(C.c_void_p(X.data_ptr()), C.c_void_p(ws.xs.data_ptr()), B, T, args.C, ws.Cxp0, g, eng.dt, st)
     run("pack", xs_pack, None, X.numel() * 4 + B * T * comp_px * ws.Cxp0 * es)
