@@ -167,7 +167,8 @@ int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, con
 /* dh (compact f32 [N][H][W][Chp], overwritten) ; dw (O,Ch), db (O) overwritten */
 int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
                   const float* dpred, float* dh, float* dw, float* db, const nint_geom* g, int dtype,
-                  void* stream);
+                  float* scratch, size_t scratch_bytes, void* stream);
+/* scratch (may be NULL): >= 256*O*(Ch+1) floats enables the tiled two-stage weight-gradient path. */
 
 /* ---- loss (train.py:102,105) ------------------------------------------------------------------ */
 /* pred (N,O,H,W) f32, y (N,O,Hc,Wc) f32; crop window [oy,oy+Hc) x [ox,ox+Wc).

@@ -62,7 +62,7 @@ SIGNATURES = {
     "nint_seq_fwd": (_I, [_PS, vp]),
     "nint_seq_bwd": (_I, [_PS, vp]),
     "nint_head_fwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, _PG, _I, vp]),
-    "nint_head_bwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, vp, vp, _PG, _I, vp]),
+    "nint_head_bwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, vp, vp, _PG, _I, vp, _SZ, vp]),
     "nint_loss_mse_l1_crop": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, _I, _I, _I, _I, vp]),
     "nint_adam_flat": (_I, [vp, vp, vp, vp, _SZ, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, vp]),
     "nint_preproc_fuse_pad": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, vp, _I, _I, _I, _I, _I, _I, vp]),

@@ -33,6 +33,48 @@ __global__ void pack_btchw_kernel(const float* __restrict__ src, void* __restric
   }
 }
 
+// Tiled variant: one workgroup per (b, t, y) row.  The NCHW side is read along x (full cache
+// lines per channel row), transposed through LDS, and the channels-last side is written as
+// 16-byte vectors of 8 (bf16) / 4 (f32) consecutive channels, i.e. whole 64-byte-chunk rows.
+template <int DT>
+__global__ __launch_bounds__(256) void pack_btchw_rows_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                             int B, int T, int C, int Cp, int H, int W, int P, int Hh,
+                                                             int Wh) {
+  extern __shared__ float tile[];              // [C][W + 1]
+  const int ld = W + 1;
+  int r = blockIdx.x;
+  const int y = r % H; r /= H;
+  const int t = r % T;
+  const int b = r / T;
+  const float* s = src + (((size_t)b * T + t) * C) * H * W + (size_t)y * W;
+  for (int i = threadIdx.x; i < C * W; i += 256) {
+    const int c = i / W, x = i - c * W;
+    tile[c * ld + x] = s[(size_t)c * H * W + x];
+  }
+  __syncthreads();
+  constexpr int V = 16 / Elem<DT>::ES;         // channels per 16-byte vector
+  const int nv = Cp / V;
+  char* d = (char*)dst + ((((size_t)t * B + b) * Hh + (y + P)) * Wh + P) * (size_t)Cp * Elem<DT>::ES;
+  for (int i = threadIdx.x; i < W * nv; i += 256) {
+    const int x = i / nv, v = i - x * nv;
+    float f[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = v * V + j;
+      f[j] = c < C ? tile[c * ld + x] : 0.f;
+    }
+    u32x4_t o;
+    if constexpr (DT == NINT_BF16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (uint32_t)f2bf(f[2 * j]) | ((uint32_t)f2bf(f[2 * j + 1]) << 16);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(uint32_t, f[j]);
+    }
+    *(u32x4_t*)(d + ((size_t)x * Cp + v * V) * Elem<DT>::ES) = o;
+  }
+}
+
 template <int DT>
 __global__ void unpack_halo_kernel(const void* __restrict__ src, float* __restrict__ dst, int n0, int N, int C,
                                    int Cp, int H, int W, int P, int Hh, int Wh) {
@@ -79,6 +121,17 @@ extern "C" int nint_pack_btchw(const float* src, void* dst, int B, int T, int C,
   if (!src || !dst || !g || B <= 0 || T <= 0 || C <= 0 || Cp < C) return NINT_E_ARG;
   const size_t total = (size_t)B * T * g->H * g->W * Cp;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
+  const size_t tile_bytes = (size_t)C * (g->W + 1) * sizeof(float);
+  if (tile_bytes <= 64 * 1024 && Cp % (dtype == NINT_BF16 ? 8 : 4) == 0) {
+    const dim3 grid((unsigned)((size_t)B * T * g->H));
+    if (dtype == NINT_BF16)
+      hipLaunchKernelGGL(pack_btchw_rows_kernel<NINT_BF16>, grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+    else
+      hipLaunchKernelGGL(pack_btchw_rows_kernel<NINT_F32>, grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+    NINT_LAUNCH_CHECK();
+    return NINT_OK;
+  }
   if (dtype == NINT_BF16)
     hipLaunchKernelGGL(pack_btchw_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
   else if (dtype == NINT_F32)
@@ -391,6 +444,71 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const void* __restrict
   }
 }
 
+// Fast path for small heads (O*(Ch+1) <= 512 outputs): every workgroup owns a pixel range, stages
+// 64 pixels of dpred and h in LDS at a time, thread (o, c) accumulates its own output over the
+// range; per-workgroup partials are folded in fixed order by head_bwd_dw_final_kernel.
+#define HEAD_DW_BLOCKS 256
+template <int DT>
+__global__ __launch_bounds__(512) void head_bwd_dw_tiled_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp,
+                                                              int O, const float* __restrict__ dpred,
+                                                              float* __restrict__ partial, int H, int W, int P, int Hh,
+                                                              int Wh) {
+  __shared__ float sd[64 * 33];                // [pixel][o] (O <= 32), padded
+  __shared__ float sh[64 * 33];                // [pixel][c] (Ch <= 32) + a constant 1 for the bias column
+  const int nout = O * (Ch + 1);
+  const int o = threadIdx.x / (Ch + 1), c = threadIdx.x % (Ch + 1);
+  const size_t npix = (size_t)N * H * W;
+  const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  float acc = 0.f;
+  for (size_t base = p0; base < p1; base += 64) {
+    const int cnt = (int)min((size_t)64, p1 - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * O; i += 512) {
+      const int oo = i / 64, pp = i % 64;
+      float v = 0.f;
+      if (pp < cnt) {
+        const size_t pix = base + pp;
+        const size_t yx = pix % ((size_t)H * W);
+        const size_t n = pix / ((size_t)H * W);
+        v = dpred[(n * O + oo) * (size_t)H * W + yx];
+      }
+      sd[pp * 33 + oo] = v;
+    }
+    for (int i = threadIdx.x; i < 64 * (Ch + 1); i += 512) {
+      const int pp = i / (Ch + 1), cc = i % (Ch + 1);
+      float v = 0.f;
+      if (pp < cnt) {
+        const size_t pix = base + pp;
+        const int x = pix % W;
+        size_t r = pix / W;
+        const int y = r % H;
+        const int n = r / H;
+        v = cc < Ch ? load_elem<DT>(h, ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp + cc) : 1.f;
+      }
+      sh[pp * 33 + cc] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nout) {
+#pragma unroll 8
+      for (int pp = 0; pp < 64; ++pp) acc += sd[pp * 33 + o] * sh[pp * 33 + c];
+    }
+  }
+  if ((int)threadIdx.x < nout) partial[(size_t)blockIdx.x * nout + threadIdx.x] = acc;
+}
+
+__global__ void head_bwd_dw_final_kernel(const float* __restrict__ partial, int nblocks, int Ch, int O,
+                                         float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nout = O * (Ch + 1);
+  if (i >= nout) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nout + i];
+  const int o = i / (Ch + 1), c = i % (Ch + 1);
+  if (c < Ch) dw[o * Ch + c] = s;
+  else db[o] = s;
+}
+
 extern "C" int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
                              const float* b, float* pred, const nint_geom* g, int dtype, void* stream) {
   if (!h_slab || !w || !pred || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
@@ -408,14 +526,25 @@ extern "C" int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp,
 
 extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
                              const float* dpred, float* dh, float* dw, float* db, const nint_geom* g, int dtype,
-                             void* stream) {
+                             float* scratch, size_t scratch_bytes, void* stream) {
   if (!h_slab || !w || !dpred || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
+  if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dh) {
     hipLaunchKernelGGL(head_bwd_dh_kernel, grid1d((size_t)N * g->H * g->W * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
     NINT_LAUNCH_CHECK();
   }
-  if (dw && db) {
+  const int nout = O * (Ch + 1);
+  if (dw && db && scratch && nout <= 512 && O <= 32 && Ch <= 32 &&
+      scratch_bytes >= (size_t)HEAD_DW_BLOCKS * nout * sizeof(float)) {
+    if (dtype == NINT_BF16)
+      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_BF16>, dim3(HEAD_DW_BLOCKS), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
+    else
+      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_F32>, dim3(HEAD_DW_BLOCKS), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
+    NINT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(nint_cdiv(nout, 256)), dim3(256), 0, st, scratch, HEAD_DW_BLOCKS, Ch, O, dw, db);
+    NINT_LAUNCH_CHECK();
+  } else if (dw && db) {
     if (dtype == NINT_BF16)
       hipLaunchKernelGGL(head_bwd_dw_kernel<NINT_BF16>, dim3(O * (Ch + 1)), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, dw, db, g->H, g->W, g->P, g->Hh, g->Wh);
     else if (dtype == NINT_F32)

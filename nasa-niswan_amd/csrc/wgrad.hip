@@ -121,6 +121,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 
   // lane constants of the transposed reads
   const int g = lane >> 4, i16 = lane & 15;
+  // per-wave constants: byte offset of each of this wave's (tap, channel tile) columns inside the
+  // cat halo image -- hoisted out of the tile loop (they cost two scalar divisions each)
+  int boff[JW];
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    const int j = min(j0 + jj, a.J - 1);
+    const int tap = j / a.NTC, ct = j - tap * a.NTC;
+    const int tyy = tap / k, txx = tap - tyy * k;
+    boff[jj] = (tyy * HWt + txx) * RB + ct * 16 * E::ES;
+  }
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int cur = (tile - t_begin) & 1;
     const bool more = tile + 1 < t_end;
@@ -146,9 +156,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         for (int jj = 0; jj < JW; ++jj) {
           const int j = j0 + jj;
           if (j < a.J) {
-            const int tap = j / a.NTC, ct = j - tap * a.NTC;
-            const int tyy = tap / k, txx = tap - tyy * k;
-            const char* bd = Bb + ((pr + tyy) * HWt + txx + 4 * g + q) * RB + ct * 32 + p8;
+            const char* bd = Bb + boff[jj] + (pr * HWt + 4 * g + q) * RB + p8;
             s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd));
             s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd + 16 * RB));
             u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
@@ -175,9 +183,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             for (int jj = 0; jj < JW; ++jj) {
               const int j = j0 + jj;
               if (j < a.J) {
-                const int tap = j / a.NTC, ct = j - tap * a.NTC;
-                const int tyy = tap / k, txx = tap - tyy * k;
-                const float bf = *(const float*)(Bb + ((pr + tyy) * HWt + txx + seg + 4 * m) * RB + (ct * 16 + i16) * 4);
+                const float bf = *(const float*)(Bb + boff[jj] + (pr * HWt + seg + 4 * m) * RB + i16 * 4);
 #pragma unroll
                 for (int i = 0; i < NTN; ++i)
                   acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);

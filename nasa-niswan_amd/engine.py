@@ -241,7 +241,8 @@ class SeqEngine:
         dw = dw_out if dw_out is not None else torch.empty(O, cfg.Ch, dtype=torch.float32, device=self.device)
         db = db_out if db_out is not None else torch.empty(O, dtype=torch.float32, device=self.device)
         check(self.lib.nint_head_bwd(ptr(ws.h[l]), ws.T * ws.B, ws.B, cfg.Ch, Chp, O, ptr(w2), ptr(dp), ptr(ws.dh[l]),
-                                     ptr(dw), ptr(db), C.byref(ws.g), self.dt, stream_ptr()), "nint_head_bwd")
+                                     ptr(dw), ptr(db), C.byref(ws.g), self.dt, ptr(self.wg_partial),
+                                     self.wg_partial.numel() * 4, stream_ptr()), "nint_head_bwd")
         return dw.view(O, cfg.Ch, 1, 1), db
 
     def backward(self, ws: Workspace, need_dx: bool, zero_state_grads: Sequence[int] = (),
