@@ -2,6 +2,7 @@
 // the hardware self-test, and the whole-sequence drivers that enqueue every launch of a
 // ConvLSTM forward (model.py:253-274) or its BPTT from C++ on one HIP stream, so the Python
 // side pays one ctypes call per pass instead of one per kernel.
+#include <stdlib.h>
 #include <string.h>
 #include "nint_common.h"
 
@@ -89,7 +90,42 @@ extern "C" int nint_selftest(float* out, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ sequence drivers
+// Layer wavefront on HIP streams: cell (t, l) only depends on (t, l-1) and (t-1, l), so layer l runs
+// on its own stream and waits for ONE event per step (recorded by the neighbouring layer).  With
+// three layers up to three cells are in flight: the tail of one launch (962 workgroups on 512
+// slots) is filled by the next, narrow layers overlap with wide ones, and in the backward pass the
+// HBM-bound pointwise kernels overlap with the MFMA-bound dgrad kernels of the other layers.
+// Layer 0 stays on the caller's stream; every pass forks from and joins back into it, so the
+// caller (and torch's stream-ordered allocator) sees ordinary single-stream semantics.
+// NINT_STREAMS=0 in the environment keeps everything on the caller's stream.
 static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
+
+struct StreamPool {
+  bool ready = false, enabled = true;
+  hipStream_t side[NINT_MAX_LAYERS] = {};
+  hipEvent_t ev[NINT_MAX_LAYERS] = {};     // "latest cell of layer l done"
+  hipEvent_t fork = nullptr;
+};
+static StreamPool g_pool[16];
+
+static int pool_get(StreamPool** out) {
+  int dev = 0;
+  NINT_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return NINT_E_ARG;
+  StreamPool& p = g_pool[dev];
+  if (!p.ready) {
+    const char* e = getenv("NINT_STREAMS");
+    p.enabled = !(e && e[0] == '0');
+    for (int l = 0; l < NINT_MAX_LAYERS; ++l) {
+      NINT_CHECK_HIP(hipStreamCreateWithFlags(&p.side[l], hipStreamNonBlocking));
+      NINT_CHECK_HIP(hipEventCreateWithFlags(&p.ev[l], hipEventDisableTiming));
+    }
+    NINT_CHECK_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
+    p.ready = true;
+  }
+  *out = &p;
+  return NINT_OK;
+}
 
 static int seq_check(const nint_seq* s) {
   if (!s || s->L < 1 || s->L > NINT_MAX_LAYERS || s->B < 1 || s->T < 1) return NINT_E_ARG;
@@ -102,15 +138,43 @@ static int seq_check(const nint_seq* s) {
   return NINT_OK;
 }
 
+// fork: side streams wait for everything already enqueued on the caller's stream
+static int fork_streams(StreamPool* p, hipStream_t st0, hipStream_t* S, int L, bool multi) {
+  S[0] = st0;
+  for (int l = 1; l < L; ++l) S[l] = multi ? p->side[l] : st0;
+  if (multi) {
+    NINT_CHECK_HIP(hipEventRecord(p->fork, st0));
+    for (int l = 1; l < L; ++l) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], p->fork, 0));
+  }
+  return NINT_OK;
+}
+
+// join: the caller's stream waits for the last launch of every side stream
+static int join_streams(StreamPool* p, hipStream_t st0, hipStream_t* S, int L, bool multi) {
+  if (!multi) return NINT_OK;
+  for (int l = 1; l < L; ++l) {
+    NINT_CHECK_HIP(hipEventRecord(p->ev[l], S[l]));
+    NINT_CHECK_HIP(hipStreamWaitEvent(st0, p->ev[l], 0));
+  }
+  return NINT_OK;
+}
+
 extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   int rc = seq_check(s);
+  if (rc != NINT_OK) return rc;
+  StreamPool* pool = nullptr;
+  rc = pool_get(&pool);
   if (rc != NINT_OK) return rc;
   const nint_geom* g = &s->g;
   const size_t es = esize(s->dtype);
   const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
-  const int B = s->B;
+  const int B = s->B, L = s->L;
+  const bool multi = pool->enabled && L > 1;
+  hipStream_t S[NINT_MAX_LAYERS];
+  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi);
+  if (rc != NINT_OK) return rc;
   for (int t = 0; t < s->T; ++t) {                               // model.py:265
-    for (int l = 0; l < s->L; ++l) {                             // model.py:267
+    for (int l = 0; l < L; ++l) {                                // model.py:267
       const nint_layer* ly = &s->layer[l];
       const char* x_slab = (l == 0)
           ? (const char*)s->xs + (size_t)t * B * halo_px * ly->Cxp * es            // x[:, t]  (model.py:266)
@@ -123,57 +187,81 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
       char* h_out = (char*)s->h[l] + (size_t)(t + 1) * hs;
       float* c_out = s->c[l] + (size_t)(t + 1) * cs;
       char* gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
-      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
+      // (t, l) needs h of (t, l-1): the latest record of ev[l-1] is exactly that cell
+      if (multi && l > 0) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));
+      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, S[l]);
       if (rc != NINT_OK) return rc;
+      if (multi && l + 1 < L) NINT_CHECK_HIP(hipEventRecord(pool->ev[l], S[l]));
     }
   }
-  return NINT_OK;
+  return join_streams(pool, (hipStream_t)stream, S, L, multi);
 }
 
 extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   int rc = seq_check(s);
   if (rc != NINT_OK) return rc;
+  StreamPool* pool = nullptr;
+  rc = pool_get(&pool);
+  if (rc != NINT_OK) return rc;
   const nint_geom* g = &s->g;
   const size_t es = esize(s->dtype);
   const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
-  const int B = s->B;
-  for (int l = 0; l < s->L; ++l)
+  const int B = s->B, L = s->L;
+  for (int l = 0; l < L; ++l)
     if (!s->gates[l] || !s->dG[l] || !s->dh[l] || !s->dc[l] || !s->dW[l] || !s->db[l]) return NINT_E_ARG;
   if (s->need_dx && !s->dx) return NINT_E_ARG;
   if (!s->wg_partial) return NINT_E_ARG;
+  // per-layer split-K workspaces so that the weight-gradient launches of different layers may overlap
+  size_t wg_off[NINT_MAX_LAYERS], wg_need = 0;
+  for (int l = 0; l < L; ++l) {
+    wg_off[l] = wg_need;
+    wg_need += (nint_wgrad_workspace_bytes(&s->layer[l], s->dtype, s->n_cu) + 255) / 256 * 256;
+  }
+  const bool multi = pool->enabled && L > 1 && wg_need <= s->wg_partial_bytes;
+  hipStream_t S[NINT_MAX_LAYERS];
+  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi);
+  if (rc != NINT_OK) return rc;
 
   for (int t = s->T - 1; t >= 0; --t) {
-    for (int l = s->L - 1; l >= 0; --l) {
+    for (int l = L - 1; l >= 0; --l) {
       const nint_layer* ly = &s->layer[l];
       const size_t cs = (size_t)B * comp_px * ly->Chp;
       const size_t Gc = 4 * (size_t)ly->Ch16;
       const char* gates = (const char*)s->gates[l] + (size_t)t * B * comp_px * Gc * es;
       char* dG = (char*)s->dG[l] + (size_t)t * B * halo_px * Gc * es;
-      // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       // bias-gradient partial rows of this (t, l): fused into the pointwise pass when the shape allows
       float* dbp = (s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0)
                        ? s->db_partial[l] + (size_t)t * NINT_DB_ROWS * Gc : nullptr;
+      // dh[l] is complete once dgrad(t, l+1) has added its x columns: latest record of ev[l+1]
+      if (multi && l + 1 < L) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l + 1], 0));
+      // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       rc = nint_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
-                                   s->dh[l], s->dc[l], dG, dbp, stream);
+                                   s->dh[l], s->dc[l], dG, dbp, S[l]);
       if (rc != NINT_OK) return rc;
       float* dx_accum = (l > 0) ? s->dh[l - 1]
                                 : (s->need_dx ? s->dx + (size_t)t * B * comp_px * ly->Cxp : nullptr);
       // at t == 0 with a zero initial state nobody consumes d/dh_{-1}
       float* dh_prev = (t == 0 && !s->has_init_state) ? nullptr : s->dh[l];
-      rc = nint_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, stream);
+      // the += into dh[l-1] must follow dgrad(t+1, l-1)'s store: at this point of the enqueue order
+      // that is the latest record of ev[l-1] (none yet at t = T-1: the fork covers it)
+      if (multi && l > 0 && t < s->T - 1) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));
+      rc = nint_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, S[l]);
       if (rc != NINT_OK) return rc;
+      if (multi) NINT_CHECK_HIP(hipEventRecord(pool->ev[l], S[l]));
     }
   }
-  // weight / bias gradients: one reduction over all T*B images per layer
-  for (int l = 0; l < s->L; ++l) {
+  // weight / bias gradients: one reduction over all T*B images per layer, on the layer's stream
+  for (int l = 0; l < L; ++l) {
     const nint_layer* ly = &s->layer[l];
     const char* x_all = (l == 0) ? (const char*)s->xs
                                  : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
     const bool fused_db = s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0;
+    float* part = multi ? (float*)((char*)s->wg_partial + wg_off[l]) : s->wg_partial;
+    const size_t part_bytes = multi ? s->wg_partial_bytes - wg_off[l] : s->wg_partial_bytes;
     rc = nint_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
-                         s->wg_partial, s->wg_partial_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
-                         s->T * NINT_DB_ROWS, stream);
+                         part, part_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
+                         s->T * NINT_DB_ROWS, S[l]);
     if (rc != NINT_OK) return rc;
   }
-  return NINT_OK;
+  return join_streams(pool, (hipStream_t)stream, S, L, multi);
 }
