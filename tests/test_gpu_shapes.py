@@ -1,0 +1,104 @@
+"""GPU parity on ragged / padded / wide shapes (every padding rule of the slab layout is exercised):
+grids that are not multiples of the 8x16 pixel tile, channel counts that are not multiples of
+16/32, hidden widths that need several column groups, wide heads, B=1, T=1 -- plus the reduced-size
+versions of BASELINE.json configs[3] (3 x hidden 128) and configs[4] (126 inputs, 200 outputs), and
+size-independent properties at the full bench size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import nasa_niswan_amd as p
+    p.load_library()
+    return p
+
+
+def run_case(pkg, C, hidden, ks, out, B, T, H, W, dtype, seed=0):
+    from oracle import convlstm_oracle as O
+    params = O.synth_params(C, hidden, ks, len(hidden), out_channels=out, seed=seed)
+    rng = np.random.default_rng(seed + 5)
+    X = torch.from_numpy(rng.standard_normal((B, T, C, H, W)).astype(np.float32))
+    wgt = torch.from_numpy(rng.standard_normal((B, out, H, W)).astype(np.float32))
+    net = pkg.ConvLSTM(C, hidden, ks, len(hidden), out_channels=out, compute_dtype=dtype).cuda()
+    net.load_state_dict(params)
+    Xd = X.cuda().requires_grad_(True)
+    pred = net(Xd)
+    (pred * wgt.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Xo = X.clone().requires_grad_(True)
+    po = O.convlstm_forward(Xo, leaf)
+    (po * wgt).sum().backward()
+    res = {"pred": (pred.detach().cpu(), po.detach()), "dX": (Xd.grad.cpu(), Xo.grad)}
+    for k, p in net.named_parameters():
+        res["grad." + k] = (p.grad.cpu(), leaf[k].grad)
+    return res
+
+
+def check(res, dtype):
+    for k, (a, b) in res.items():
+        a, b = a.double().numpy(), b.double().numpy()
+        if dtype == "f32":
+            err, ref = np.abs(a - b).max(), np.abs(b).max()
+            print(f"  {k}: max abs err {err:.2e} (ref max {ref:.2e})")
+            assert err <= 1e-3 * ref + 1e-5, (k, err, ref)
+        else:
+            r = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+            print(f"  {k}: rel-L2 {r:.2e}")
+            assert r <= 5e-2, (k, r)
+
+
+CASES = {
+    # name: (C, hidden, ks, out, B, T, H, W)
+    "ragged-grid-odd-channels": (7, [24, 16], [3, 5], 1, 3, 2, 11, 19),
+    "batch1-T1": (5, [16], [5], 1, 1, 1, 9, 17),
+    "k1-and-k3": (4, [16, 8], [1, 3], 2, 2, 2, 8, 16),
+    "cfg3-reduced (3 x hidden 128, k3)": (6, [128, 128, 128], [3, 3, 3], 1, 1, 2, 10, 18),
+    "cfg4-reduced (126 in, 200 out)": (126, [64, 32, 16], [5, 3, 3], 200, 1, 2, 12, 20),
+    "wide-hidden-48": (3, [48], [3], 3, 2, 2, 13, 33),
+}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_shapes_vs_oracle(pkg, name, dtype):
+    check(run_case(pkg, *CASES[name], dtype), dtype)
+
+
+def test_full_size_properties(pkg):
+    """100x154 padded grid, T=12, C=62, out=20 (the bench workload) at B=2: the oracle needs minutes
+    here, so check what must hold at any size: run-to-run bitwise determinism, batch independence
+    (a sample's result does not depend on its batch mates) and agreement of the f32 and bf16 paths."""
+    torch.manual_seed(0)
+    C, hidden, ks, out, B, T, H, W = 62, [64, 32, 16], [5, 3, 3], 20, 2, 12, 100, 154
+    X = torch.randn(B, T, C, H, W, device="cuda")
+    wgt = torch.randn(B, out, H, W, device="cuda")
+    nets = {}
+    for dt in ("f32", "bf16"):
+        torch.manual_seed(1)
+        nets[dt] = pkg.ConvLSTM(C, hidden, ks, 3, out_channels=out, compute_dtype=dt).cuda()
+    outs, grads = {}, {}
+    for dt, net in nets.items():
+        for rep in range(2):
+            net.zero_grad()
+            pred = net(X)
+            (pred * wgt).sum().backward()
+            g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+            if rep == 0:
+                outs[dt], grads[dt] = pred.detach().clone(), g.clone()
+            else:
+                assert torch.equal(pred, outs[dt]) and torch.equal(g, grads[dt]), f"{dt}: not deterministic"
+        with torch.no_grad():
+            single = net(X[1:2])
+        assert torch.equal(single, outs[dt][1:2]), f"{dt}: batch dependence"
+    r = float((outs["bf16"] - outs["f32"]).norm() / outs["f32"].norm())
+    rg = float((grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm())
+    print(f"  bf16 vs f32 at full size: pred rel-L2 {r:.2e}, grads rel-L2 {rg:.2e}")
+    assert r < 2e-2 and rg < 5e-2
+    assert torch.isfinite(grads["f32"]).all()
