@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="cfg1-20level", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,8 +101,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL on ROCm
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -114,13 +116,13 @@ def main():
     B = args.batch
     torch.manual_seed(0)                                    # identical init on every rank (utils.py:77-88)
     model = pkg.ConvLSTM(C, list(hidden), list(ks), len(hidden), out_channels=out, compute_dtype=args.dtype).to(dev)
-    trainer = FusedTrainer(model, lr=1e-3, betas=(0.5, 0.999), halo=halo)
+    trainer = FusedTrainer(model, lr=1e-3, betas=(0.5, 0.999), halo=halo, distributed=(world > 1 or args.force_dist))
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)   # each rank its own shard of synthetic data
     X = torch.randn(B, T, C, Hp, Wp, device=dev, generator=gen)
     y = torch.randn(B, out, grid[0], grid[1], device=dev, generator=gen)
 
     def sync():
-        if world > 1:
+        if world > 1 or args.force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +134,7 @@ def main():
         loss = trainer.step(X, y)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or args.force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -193,7 +195,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

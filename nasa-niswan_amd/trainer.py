@@ -44,12 +44,13 @@ class FusedTrainer:
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if distributed else 1
+        self.distributed = bool(distributed)      # True also for a 1-rank group (exercises the collective path)
         L = model.num_layers
         self._dW = [self.flat.grad_view(2 * l) for l in range(L)]
         self._db = [self.flat.grad_view(2 * l + 1) for l in range(L)]
         self._dw_head = self.flat.grad_view(2 * L)
         self._db_head = self.flat.grad_view(2 * L + 1)
-        if self.world > 1:
+        if self.distributed:
             # identical initial weights on every rank (the reference seeds identically, utils.py:77-88)
             dist.broadcast(self.flat.data, src=0, group=process_group)
 
@@ -89,7 +90,7 @@ class FusedTrainer:
                 ws.dh[l].zero_()
         eng.backward(ws, False, dW_out=self._dW, db_out=self._db)
         eng.release(ws)
-        if self.world > 1:
+        if self.distributed:
             self.dist.all_reduce(self.flat.grad, op=self.dist.ReduceOp.SUM, group=self.pg)   # RCCL over xGMI
         self.optimizer.step(grad_scale=1.0 / self.world)
         return self.scratch[0]

@@ -114,3 +114,22 @@ def test_train_py_end_to_end(pkg, tmp_path, monkeypatch):
     logger2 = T.main(T.get_arguments(argv[:-4] + ["--synthetic-steps", "36", "--dtype", "f32", "--use-checkpoint",
                                                    "--restore-from", str(snap / "epoch-010"), "--num-epochs", "1"]))
     assert logger2["MSELoss"][0] < logger["MSELoss"][0]
+
+
+def test_bench_under_torchrun_with_rccl_group(pkg):
+    """The N>1 launch contract on a 1-GPU box: torch.distributed.run, one rank, RCCL process group
+    forced on, so init / broadcast / all-reduce / barrier / MAX-reduce of the timing all execute."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--force-dist", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1" and d["scaling"] == "weak"
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
