@@ -152,19 +152,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
           u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
           af[i] = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
         }
+        // branch-free: columns past J are clamped duplicates (boff) whose accumulators are never
+        // flushed, so all JW fragment reads of the K-step can be in flight ahead of its MFMAs
+        u32x4_t bf[JW];
 #pragma unroll
         for (int jj = 0; jj < JW; ++jj) {
-          const int j = j0 + jj;
-          if (j < a.J) {
-            const char* bd = Bb + boff[jj] + (pr * HWt + 4 * g + q) * RB + p8;
-            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd));
-            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd + 16 * RB));
-            u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-            const u32x4_t bf = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
-#pragma unroll
-            for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf, acc[i][jj]);
-          }
+          const char* bd = Bb + boff[jj] + (pr * HWt + 4 * g + q) * RB + p8;
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd + 16 * RB));
+          u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+          bf[jj] = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
         }
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+          for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
       }
     } else {
 #pragma unroll 1
@@ -181,13 +183,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
               af[i] = *(const float*)(Ab + (pr * 32 + seg + 4 * m) * RA + (i * 16 + i16) * 4);
 #pragma unroll
             for (int jj = 0; jj < JW; ++jj) {
-              const int j = j0 + jj;
-              if (j < a.J) {
-                const float bf = *(const float*)(Bb + boff[jj] + (pr * HWt + seg + 4 * m) * RB + i16 * 4);
+              const float bf = *(const float*)(Bb + boff[jj] + (pr * HWt + seg + 4 * m) * RB + i16 * 4);
 #pragma unroll
-                for (int i = 0; i < NTN; ++i)
-                  acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
-              }
+              for (int i = 0; i < NTN; ++i)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
             }
           }
         }
