@@ -19,18 +19,21 @@
 //     summed through LDS once at the end (narrow-N layers: layer 3, dgrad of layer 1).
 //   - the i,f,g,o tiles of one hidden channel sit in the same lane (column order
 //     n' = (cblock*4+gate)*16+col), so the LSTM epilogue needs no cross-lane traffic.
+#include <stdlib.h>
 #include "nint_common.h"
 
 enum { EPI_LSTM = 0, EPI_DGRAD = 1 };
 
-constexpr int MT = 8;   // row tiles per wave = rows of the pixel tile
+// MT (template) = row tiles per wave = rows of the pixel tile: 8 for the wide launches (one weight
+// stream per 128 pixels), 4 for the short-K launches of the narrow layers, whose time is all halo
+// fill + epilogue latency: smaller tiles put 3-4 workgroups per CU in flight instead of 2.
 #ifndef NINT_BD
 #define NINT_BD 3
 #endif
 constexpr int BD = NINT_BD;   // depth of the per-wave weight-fragment ring
 
-template <int DT, int EPI, int WN, int WK, int NTW>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+template <int DT, int EPI, int WN, int WK, int NTW, int MT>
+__global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvArgs a) {
   static_assert(WN * WK == 4, "four waves per workgroup");
   static_assert(EPI != EPI_LSTM || NTW % 4 == 0, "LSTM epilogue needs the 4 gate tiles in one wave");
   constexpr int NTH = 256;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------ host side
-template <int DT, int EPI, int WN, int WK, int NTW>
+template <int DT, int EPI, int WN, int WK, int NTW, int MT>
 static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   const int NHP = (MT + 2 * a.p) * (16 + 2 * a.p);
   a.nhp_pad = nint_round_up(NHP, 16);
@@ -275,7 +278,7 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   if (lds > 160 * 1024) return NINT_E_LDS;
   a.tiles_x = nint_cdiv(a.W, 16);
   a.tiles_y = nint_cdiv(a.H, MT);
-  auto kern = conv_igemm_kernel<DT, EPI, WN, WK, NTW>;
+  auto kern = conv_igemm_kernel<DT, EPI, WN, WK, NTW, MT>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid(a.tiles_x * a.tiles_y * N, ngroups_y), block(256);
@@ -287,22 +290,25 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
 template <int DT, int EPI>
 static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   if (ntiles <= 0) return NINT_OK;
+  // short-K launches (narrow layers) take 4-row tiles; NINT_MT=4|8 in the environment overrides
+  static const int mt_env = [] { const char* e = getenv("NINT_MT"); return e ? atoi(e) : 0; }();
+  const bool mt4 = mt_env ? mt_env == 4 : ((a.nchunk0 + a.nchunk1) * a.taps <= 48 || ntiles <= 4);
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;
-    if (cbs % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 4>(a, N, cbs / 4, st);
-    if (cbs % 2 == 0) return launch_cfg<DT, EPI, 2, 2, 4>(a, N, cbs / 2, st);
-    return launch_cfg<DT, EPI, 1, 4, 4>(a, N, cbs, st);
+    if (cbs % 4 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, cbs / 4, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, cbs / 4, st);
+    if (cbs % 2 == 0) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st);
+    return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st);
   } else {
     // (WN, NTW) with WN*NTW dividing the tile count, widest first; leftover waves split K
-    if (ntiles % 16 == 0) return launch_cfg<DT, EPI, 4, 1, 4>(a, N, ntiles / 16, st);
-    if (ntiles % 12 == 0) return launch_cfg<DT, EPI, 4, 1, 3>(a, N, ntiles / 12, st);
-    if (ntiles % 8 == 0) return launch_cfg<DT, EPI, 2, 2, 4>(a, N, ntiles / 8, st);
-    if (ntiles % 6 == 0) return launch_cfg<DT, EPI, 2, 2, 3>(a, N, ntiles / 6, st);
-    if (ntiles % 4 == 0) return launch_cfg<DT, EPI, 1, 4, 4>(a, N, ntiles / 4, st);
-    if (ntiles % 3 == 0) return launch_cfg<DT, EPI, 1, 4, 3>(a, N, ntiles / 3, st);
-    if (ntiles % 2 == 0) return launch_cfg<DT, EPI, 1, 4, 2>(a, N, ntiles / 2, st);
-    return launch_cfg<DT, EPI, 1, 4, 1>(a, N, ntiles, st);
+    if (ntiles % 16 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, ntiles / 16, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, ntiles / 16, st);
+    if (ntiles % 12 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 3, 4>(a, N, ntiles / 12, st) : launch_cfg<DT, EPI, 4, 1, 3, 8>(a, N, ntiles / 12, st);
+    if (ntiles % 8 == 0) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, ntiles / 8, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, ntiles / 8, st);
+    if (ntiles % 6 == 0) return mt4 ? launch_cfg<DT, EPI, 2, 2, 3, 4>(a, N, ntiles / 6, st) : launch_cfg<DT, EPI, 2, 2, 3, 8>(a, N, ntiles / 6, st);
+    if (ntiles % 4 == 0) return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, ntiles / 4, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, ntiles / 4, st);
+    if (ntiles % 3 == 0) return mt4 ? launch_cfg<DT, EPI, 1, 4, 3, 4>(a, N, ntiles / 3, st) : launch_cfg<DT, EPI, 1, 4, 3, 8>(a, N, ntiles / 3, st);
+    if (ntiles % 2 == 0) return mt4 ? launch_cfg<DT, EPI, 1, 4, 2, 4>(a, N, ntiles / 2, st) : launch_cfg<DT, EPI, 1, 4, 2, 8>(a, N, ntiles / 2, st);
+    return mt4 ? launch_cfg<DT, EPI, 1, 4, 1, 4>(a, N, ntiles, st) : launch_cfg<DT, EPI, 1, 4, 1, 8>(a, N, ntiles, st);
   }
 }
 
