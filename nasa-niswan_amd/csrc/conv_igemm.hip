@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   static_assert(EPI != EPI_LSTM || NTW % 4 == 0, "LSTM epilogue needs the 4 gate tiles in one wave");
   constexpr int NTH = 256;
   constexpr int NTWG = WN * NTW;   // n-tiles per workgroup
+  constexpr int Q = MT / WK;       // rows whose epilogue this wave runs (K-slice waves split the rows)
+  static_assert(MT % WK == 0, "K-slice waves split the tile rows evenly");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -69,6 +71,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
                                    ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.pix_stride1
                              : nullptr;
   const int a_lane_off = (lane >> 4) * plane + (lane & 15) * 16;
+  // local accumulator row i of K-slice wk is tile row (i + wk*Q) % MT: the rows a wave owns after the
+  // K-slice exchange are then always its local rows 0..Q-1 (static register indexing)
+  int rowoff[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rowoff[i] = ((i + wk * Q) % MT) * HWt * 16;
   const char* Bwave = a.Bp + (size_t)nt0 * 1024 + lane * 16;
   const size_t bstep = (size_t)a.NTt * 1024;   // bytes between consecutive K-steps in Bp
 
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
         const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
         u32x4_t af[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + i * HWt * 16);
+        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
         const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
         u32x4_t af[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + i * HWt * 16);
+        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -163,27 +170,31 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   }
 
   // ------------------------------------------------------------------ K-slice reduction
+  // Every wave OWNS Q = MT/WK of the rows: its local accumulators 0..Q-1 (local row ii of slice
+  // wk is tile row (ii + wk*Q) % MT, see rowoff above), so the epilogue is spread over all four
+  // waves.  One exchange through LDS: each wave parks its MT-Q foreign rows (tile-major,
+  // lane-linear 1 KiB tiles), barrier, each wave adds the WK-1 foreign partials of its own rows.
   if constexpr (WK > 1) {
-    // rounds r = 1..WK-1: the waves of slice r park their accumulators in LDS (tile-major, lane-linear),
-    // the slice-0 wave of the same column group adds them.
-    for (int r = 1; r < WK; ++r) {
-      __syncthreads();                         // LDS free (image reads / previous round done)
-      char* slot = smem + (size_t)wn * (MT * NTW * 1024) + lane * 16;
-      if (wk == r) {
+    constexpr int FR = MT - Q;                 // foreign rows per wave
+    __syncthreads();                           // every wave is done reading the A image
+    char* mine = smem + (size_t)((wn * WK + wk) * FR * NTW) * 1024 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int ii = Q; ii < MT; ++ii)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) *(f32x4_t*)(slot + (i * NTW + j) * 1024) = acc[i][j];
-      }
-      __syncthreads();
-      if (wk == 0) {
+      for (int j = 0; j < NTW; ++j) *(f32x4_t*)(mine + ((ii - Q) * NTW + j) * 1024) = acc[ii][j];
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int d = 1; d < WK; ++d) {
+      const int src = (wk + d) % WK;           // slice whose partials are added now
+      // my local row ii is tile row (ii + wk*Q) % MT = local row (ii + (wk-src)*Q) mod MT of `src`
+      const int shift = ((wk - src + WK) % WK) * Q;      // in [Q, MT): always a foreign row there
+      const char* theirs = smem + (size_t)((wn * WK + src) * FR * NTW) * 1024 + lane * 16;
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] += *(const f32x4_t*)(slot + (i * NTW + j) * 1024);
-      }
+      for (int ii = 0; ii < Q; ++ii)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[ii][j] += *(const f32x4_t*)(theirs + ((ii + shift - Q) * NTW + j) * 1024);
     }
-    if (wk != 0) return;
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -204,8 +215,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       const f32x4_t bg = *(const f32x4_t*)(a.bias + (cblock * 4 + 2) * 16 + c4);
       const f32x4_t bo = *(const f32x4_t*)(a.bias + (cblock * 4 + 3) * 16 + c4);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int y = y0 + i;
+      for (int i = 0; i < Q; ++i) {
+        const int y = y0 + (i + wk * Q) % MT;
         if (y < a.H && x < a.W) {
           const size_t pix = ((size_t)img * a.H + y) * a.W + x;
           f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
@@ -235,8 +246,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int y = y0 + i;
+    for (int i = 0; i < Q; ++i) {
+      const int y = y0 + (i + wk * Q) % MT;
       if (y < a.H && x < a.W) {
         const size_t pix = ((size_t)img * a.H + y) * a.W + x;
 #pragma unroll
@@ -263,7 +274,7 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   a.nhp_pad = nint_round_up(NHP, 16);
   const int chunk_bytes = 4 * a.nhp_pad * 16;
   const int nchunks = a.nchunk0 + a.nchunk1;
-  const int red_bytes = WK > 1 ? WN * MT * NTW * 1024 : 0;
+  const int red_bytes = WK > 1 ? WN * WK * (MT - MT / WK) * NTW * 1024 : 0;   // K-slice exchange buffer
   // as many channel chunks per fill as fit in ~72 KiB (two workgroups per CU stay resident)
   int cpf = (72 * 1024) / chunk_bytes;
   if (cpf < 1) cpf = 1;
