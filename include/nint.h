@@ -156,6 +156,17 @@ int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
 /* db_partial/db_rows: the rows written by the fused pointwise-backward launches of all time steps
  * (db = their column sum); NULL -> db is computed by a column-sum pass over dG instead. */
 
+/* The same reduction in time chunks (the sequence driver overlaps early chunks with the rest of
+ * BPTT): every chunk writes its slabs with the layout of the plan for N_plan images; finalize folds
+ * `nchunks` chunks spaced chunk_stride_floats apart. */
+int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
+                            const void* dG, const void* x_slab, const void* h_slab, float* partial,
+                            size_t partial_bytes, int n_cu, void* stream);
+int nint_conv_wgrad_finalize(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int nchunks,
+                             size_t chunk_stride_floats, int N_total, const void* dG, float* dW, float* db,
+                             float* partial, int n_cu, const float* db_partial, int db_rows, void* stream);
+#define NINT_WGRAD_CHUNKS 4   /* time chunks nint_seq_bwd uses when the workspace allows */
+
 /* ---- whole-sequence drivers (model.py:253-274 and its BPTT), all launches from C++ ---------- */
 int nint_seq_fwd(const nint_seq* s /*host*/, void* stream);
 int nint_seq_bwd(const nint_seq* s /*host*/, void* stream);

@@ -14,6 +14,7 @@ NINT_F32, NINT_BF16 = 0, 1
 NINT_MAX_LAYERS = 8
 NINT_LOSS_SCRATCH_FLOATS = 2050
 NINT_DB_ROWS = 1024
+NINT_WGRAD_CHUNKS = 4
 
 vp = C.c_void_p
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     "nint_conv_dgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp]),
     "nint_wgrad_workspace_bytes": (_SZ, [_PL, _I, _I]),
     "nint_conv_wgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, _SZ, _I, vp, _I, vp]),
+    "nint_conv_wgrad_partial": (_I, [_PL, _PG, _I, _I, _I, _I, vp, vp, vp, vp, _SZ, _I, vp]),
+    "nint_conv_wgrad_finalize": (_I, [_PL, _PG, _I, _I, _I, _SZ, _I, vp, vp, vp, vp, _I, vp, _I, vp]),
     "nint_seq_fwd": (_I, [_PS, vp]),
     "nint_seq_bwd": (_I, [_PS, vp]),
     "nint_head_fwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, _PG, _I, vp]),

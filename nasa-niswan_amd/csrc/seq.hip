@@ -97,13 +97,15 @@ extern "C" int nint_selftest(float* out, void* stream) {
 // HBM-bound pointwise kernels overlap with the MFMA-bound dgrad kernels of the other layers.
 // Layer 0 stays on the caller's stream; every pass forks from and joins back into it, so the
 // caller (and torch's stream-ordered allocator) sees ordinary single-stream semantics.
-// NINT_STREAMS=0 in the environment keeps everything on the caller's stream.
+// Opt-in with NINT_STREAMS=1 in the environment; by default everything stays on the caller's stream.
 static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
 
 struct StreamPool {
   bool ready = false, enabled = true;
   hipStream_t side[NINT_MAX_LAYERS] = {};
   hipEvent_t ev[NINT_MAX_LAYERS] = {};     // "latest cell of layer l done"
+  hipStream_t wg[NINT_MAX_LAYERS] = {};    // low-priority streams of the chunked weight-gradient launches
+  hipEvent_t evw[NINT_MAX_LAYERS] = {};
   hipEvent_t fork = nullptr;
 };
 static StreamPool g_pool[16];
@@ -114,11 +116,18 @@ static int pool_get(StreamPool** out) {
   if (dev < 0 || dev >= 16) return NINT_E_ARG;
   StreamPool& p = g_pool[dev];
   if (!p.ready) {
+    // opt-in: with the current kernels (3 workgroups per CU, short launches) the wavefront measures
+    // within noise of the single-stream order on MI355X, so the simpler order is the default
     const char* e = getenv("NINT_STREAMS");
-    p.enabled = !(e && e[0] == '0');
+    p.enabled = (e && e[0] == '1');
+    int prio_least = 0, prio_greatest = 0;
+    NINT_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     for (int l = 0; l < NINT_MAX_LAYERS; ++l) {
       NINT_CHECK_HIP(hipStreamCreateWithFlags(&p.side[l], hipStreamNonBlocking));
       NINT_CHECK_HIP(hipEventCreateWithFlags(&p.ev[l], hipEventDisableTiming));
+      // the weight-gradient chunks are throughput filler behind the latency-critical BPTT chain
+      NINT_CHECK_HIP(hipStreamCreateWithPriority(&p.wg[l], hipStreamNonBlocking, prio_least));
+      NINT_CHECK_HIP(hipEventCreateWithFlags(&p.evw[l], hipEventDisableTiming));
     }
     NINT_CHECK_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
     p.ready = true;
@@ -211,16 +220,30 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     if (!s->gates[l] || !s->dG[l] || !s->dh[l] || !s->dc[l] || !s->dW[l] || !s->db[l]) return NINT_E_ARG;
   if (s->need_dx && !s->dx) return NINT_E_ARG;
   if (!s->wg_partial) return NINT_E_ARG;
-  // per-layer split-K workspaces so that the weight-gradient launches of different layers may overlap
-  size_t wg_off[NINT_MAX_LAYERS], wg_need = 0;
+  // Weight gradients are reduced in NCH time chunks: chunk c (time steps [T*c/NCH, T*(c+1)/NCH)) is
+  // launched on a low-priority stream as soon as BPTT has passed its first time step, so most of the
+  // weight-gradient work runs inside the idle phases of the remaining (latency-bound) BPTT chain.
+  // Each (layer, chunk) has its own split-K workspace.
+  // NINT_WG_CHUNKS (environment) = number of time chunks, 1..NINT_WGRAD_CHUNKS; default 1: measured on
+  // MI355X the chunk launches steal CU slots from the BPTT chain and lengthen the step
+  static const int nch_env = [] { const char* e = getenv("NINT_WG_CHUNKS"); int v = e ? atoi(e) : 1;
+                                  return v < 1 ? 1 : (v > NINT_WGRAD_CHUNKS ? NINT_WGRAD_CHUNKS : v); }();
+  int nch = s->T < nch_env ? s->T : nch_env;
+  size_t wg_stride[NINT_MAX_LAYERS], wg_off[NINT_MAX_LAYERS], wg_need = 0;
   for (int l = 0; l < L; ++l) {
+    wg_stride[l] = (nint_wgrad_workspace_bytes(&s->layer[l], s->dtype, s->n_cu) + 255) / 256 * 256;
     wg_off[l] = wg_need;
-    wg_need += (nint_wgrad_workspace_bytes(&s->layer[l], s->dtype, s->n_cu) + 255) / 256 * 256;
+    wg_need += wg_stride[l] * nch;
   }
-  const bool multi = pool->enabled && L > 1 && wg_need <= s->wg_partial_bytes;
+  const bool multi = pool->enabled && wg_need <= s->wg_partial_bytes;
+  if (!multi) nch = 1;
+  const int chunk_steps = nint_cdiv(s->T, nch);          // time steps per chunk (the last may be shorter)
+  nch = nint_cdiv(s->T, chunk_steps);
+  const int N_plan = chunk_steps * B;
   hipStream_t S[NINT_MAX_LAYERS];
-  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi);
+  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi && L > 1);
   if (rc != NINT_OK) return rc;
+  const bool wave = multi && L > 1;                       // layer wavefront on side streams
 
   for (int t = s->T - 1; t >= 0; --t) {
     for (int l = L - 1; l >= 0; --l) {
@@ -233,7 +256,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       float* dbp = (s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0)
                        ? s->db_partial[l] + (size_t)t * NINT_DB_ROWS * Gc : nullptr;
       // dh[l] is complete once dgrad(t, l+1) has added its x columns: latest record of ev[l+1]
-      if (multi && l + 1 < L) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l + 1], 0));
+      if (wave && l + 1 < L) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l + 1], 0));
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       rc = nint_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
                                    s->dh[l], s->dc[l], dG, dbp, S[l]);
@@ -244,24 +267,47 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       float* dh_prev = (t == 0 && !s->has_init_state) ? nullptr : s->dh[l];
       // the += into dh[l-1] must follow dgrad(t+1, l-1)'s store: at this point of the enqueue order
       // that is the latest record of ev[l-1] (none yet at t = T-1: the fork covers it)
-      if (multi && l > 0 && t < s->T - 1) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));
+      if (wave && l > 0 && t < s->T - 1) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));
       rc = nint_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, S[l]);
       if (rc != NINT_OK) return rc;
-      if (multi) NINT_CHECK_HIP(hipEventRecord(pool->ev[l], S[l]));
+      if (wave) NINT_CHECK_HIP(hipEventRecord(pool->ev[l], S[l]));
+      if (multi && nch > 1 && t % chunk_steps == 0) {
+        // dG[l] of chunk c = t / chunk_steps is complete: reduce it now, behind the rest of BPTT
+        const int c = t / chunk_steps;
+        const int t_hi = (t + chunk_steps < s->T) ? t + chunk_steps : s->T;
+        NINT_CHECK_HIP(hipEventRecord(pool->evw[l], S[l]));
+        NINT_CHECK_HIP(hipStreamWaitEvent(pool->wg[l], pool->evw[l], 0));
+        const char* x_all = (l == 0) ? (const char*)s->xs
+                                     : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
+        rc = nint_conv_wgrad_partial(ly, g, s->dtype, N_plan, t * B, (t_hi - t) * B, s->dG[l], x_all, s->h[l],
+                                     (float*)((char*)s->wg_partial + wg_off[l] + (size_t)c * wg_stride[l]), wg_stride[l],
+                                     s->n_cu, pool->wg[l]);
+        if (rc != NINT_OK) return rc;
+      }
     }
   }
-  // weight / bias gradients: one reduction over all T*B images per layer, on the layer's stream
+  // fold the chunks (and the bias-gradient partial rows) of every layer
   for (int l = 0; l < L; ++l) {
     const nint_layer* ly = &s->layer[l];
-    const char* x_all = (l == 0) ? (const char*)s->xs
-                                 : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
     const bool fused_db = s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0;
-    float* part = multi ? (float*)((char*)s->wg_partial + wg_off[l]) : s->wg_partial;
-    const size_t part_bytes = multi ? s->wg_partial_bytes - wg_off[l] : s->wg_partial_bytes;
-    rc = nint_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
-                         part, part_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
-                         s->T * NINT_DB_ROWS, S[l]);
-    if (rc != NINT_OK) return rc;
+    if (multi && nch > 1) {
+      rc = nint_conv_wgrad_finalize(ly, g, s->dtype, N_plan, nch, wg_stride[l] / sizeof(float), s->T * B, s->dG[l], s->dW[l],
+                                    s->db[l], (float*)((char*)s->wg_partial + wg_off[l]), s->n_cu,
+                                    fused_db ? s->db_partial[l] : nullptr, s->T * NINT_DB_ROWS, pool->wg[l]);
+      if (rc != NINT_OK) return rc;
+      NINT_CHECK_HIP(hipEventRecord(pool->evw[l], pool->wg[l]));
+      NINT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, pool->evw[l], 0));
+    } else {
+      const char* x_all = (l == 0) ? (const char*)s->xs
+                                   : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
+      // with the layer wavefront the three launches run concurrently: each layer has its own workspace
+      float* part = wave ? (float*)((char*)s->wg_partial + wg_off[l]) : s->wg_partial;
+      const size_t part_bytes = wave ? wg_stride[l] : s->wg_partial_bytes;
+      rc = nint_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
+                           part, part_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
+                           s->T * NINT_DB_ROWS, S[l]);
+      if (rc != NINT_OK) return rc;
+    }
   }
-  return join_streams(pool, (hipStream_t)stream, S, L, multi);
+  return join_streams(pool, (hipStream_t)stream, S, L, wave);
 }

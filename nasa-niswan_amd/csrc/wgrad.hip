@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // the slab layout [block][j][n'loc 64][c 16] -> every split is read fully coalesced, in fixed order
 // (bitwise reproducible); only the single write per weight is scattered.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Cx, int Ch, int Ch16, int k,
-                                    int NB, int CB, int NTC, int splits, int is_h) {
+                                    int NB, int CB, int NTC, int splits, int is_h, int nchunks, size_t chunk_stride) {
   const int taps = k * k, Ctot = Cx + Ch;
   const int J = taps * NTC;
   const size_t slab = (size_t)NB * CB * J * 1024;
@@ -232,7 +232,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
     if (cc >= Csrc || ch >= Ch) continue;               // padding rows / columns
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += part[sp * slab + i];
+    for (int ch_ = 0; ch_ < nchunks; ++ch_)
+      for (int sp = 0; sp < splits; ++sp) s += part[ch_ * chunk_stride + sp * slab + i];
     const int ic = is_h ? Cx + cc : cc;
     dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
   }
@@ -353,13 +354,16 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   return NINT_OK;
 }
 
-extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG,
-                               const void* x_slab, const void* h_slab, float* dW, float* db, float* partial,
-                               size_t partial_bytes, int n_cu, const float* db_partial, int db_rows, void* stream) {
-  if (!ly || !g || !dG || !x_slab || !h_slab || !dW || !db || !partial || N <= 0) return NINT_E_ARG;
+// One chunk of a (possibly time-chunked) weight-gradient reduction: images [n_first, n_first+N) of the
+// stacks, split-K slabs written to `partial` with the layout of the plan for N_plan images (so that
+// every chunk of a reduction has the same layout and nint_conv_wgrad_finalize can fold them).
+extern "C" int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
+                                       const void* dG, const void* x_slab, const void* h_slab, float* partial,
+                                       size_t partial_bytes, int n_cu, void* stream) {
+  if (!ly || !g || !dG || !x_slab || !h_slab || !partial || N <= 0 || N_plan < N || n_first < 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   WgPlan pl;
-  int rc = wg_plan(ly, dtype, n_cu, N, g, &pl);
+  int rc = wg_plan(ly, dtype, n_cu, N_plan, g, &pl);
   if (rc != NINT_OK) return rc;
   if (pl.total_floats * sizeof(float) > partial_bytes) return NINT_E_ARG;
   const int es = dtype == NINT_BF16 ? 2 : 4;
@@ -367,19 +371,20 @@ extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dty
   hipStream_t st = (hipStream_t)stream;
   for (int part = 0; part < 2; ++part) {
     WgradArgs a = {};
-    a.dG = (const char*)dG;
     a.dG_pix_stride = Gc * es;
     a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
+    a.dG = (const char*)dG + (size_t)n_first * a.dG_img_stride;
     const int Cp = part == 0 ? ly->Cxp : ly->Chp;
-    a.src = (const char*)(part == 0 ? x_slab : h_slab);
     a.src_pix_stride = Cp * es;
     a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
+    a.src = (const char*)(part == 0 ? x_slab : h_slab) + (size_t)n_first * a.src_img_stride;
     a.partial = partial + (part == 0 ? 0 : pl.off_h);
     a.CB = part == 0 ? pl.CBx : pl.CBh;
     a.NTC = pl.NTC; a.J = pl.J;
     a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
     a.P = g->P; a.Wh = g->Wh;
-    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ntiles = pl.ntiles;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
+    a.ntiles = N * pl.tiles_x * pl.tiles_y;           // this chunk; later splits may be empty (they flush zeros)
     a.tiles_per_split = part == 0 ? pl.tps_x : pl.tps_h;
     const int splits = part == 0 ? pl.splits_x : pl.splits_h;
     const int nblk = pl.NB * a.CB;
@@ -389,28 +394,53 @@ extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dty
       rc = pl.JW == 5 ? launch_wgrad<NINT_F32, 5>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 7>(a, splits, nblk, st);
     if (rc != NINT_OK) return rc;
   }
+  return NINT_OK;
+}
+
+// Fold the slabs of `nchunks` chunks (chunk c at partial + c*chunk_stride_floats) into dW, and the
+// bias gradient from the fused pointwise partial rows (or a column-sum pass over dG).
+extern "C" int nint_conv_wgrad_finalize(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int nchunks,
+                                        size_t chunk_stride_floats, int N_total, const void* dG, float* dW, float* db,
+                                        float* partial, int n_cu, const float* db_partial, int db_rows, void* stream) {
+  if (!ly || !g || !dW || !db || !partial || nchunks < 1 || N_plan <= 0) return NINT_E_ARG;
+  if (!db_partial && !dG) return NINT_E_ARG;
+  WgPlan pl;
+  int rc = wg_plan(ly, dtype, n_cu, N_plan, g, &pl);
+  if (rc != NINT_OK) return rc;
+  const int Gc = 4 * ly->Ch16;
+  hipStream_t st = (hipStream_t)stream;
   for (int part = 0; part < 2; ++part) {
     const int CB = part == 0 ? pl.CBx : pl.CBh;
     const size_t slab = (size_t)pl.NB * CB * pl.J * 1024;
     size_t gsz = (slab + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, st, partial + (part == 0 ? 0 : pl.off_h), dW,
-                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, part == 0 ? pl.splits_x : pl.splits_h, part);
+                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, part == 0 ? pl.splits_x : pl.splits_h, part,
+                       nchunks, chunk_stride_floats);
     NINT_LAUNCH_CHECK();
   }
   {
-    float* dbp = partial + pl.off_db;
+    float* dbp = partial + pl.off_db;          // (chunk 0's tail is the scratch of the bias fold)
     dim3 grid(pl.db_rows, Gc / 64);
     if (db_partial) {
       hipLaunchKernelGGL(rowsum_partial_kernel, grid, dim3(256), 0, st, db_partial, dbp, db_rows, Gc);
     } else if (dtype == NINT_BF16) {
-      hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+      hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N_total, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
     } else {
-      hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+      hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N_total, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
     }
     NINT_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(nint_cdiv(4 * ly->Ch, 256)), dim3(256), 0, st, dbp, db, ly->Ch, Gc, pl.db_rows);
     NINT_LAUNCH_CHECK();
   }
   return NINT_OK;
+}
+
+extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG,
+                               const void* x_slab, const void* h_slab, float* dW, float* db, float* partial,
+                               size_t partial_bytes, int n_cu, const float* db_partial, int db_rows, void* stream) {
+  if (!dW || !db) return NINT_E_ARG;
+  int rc = nint_conv_wgrad_partial(ly, g, dtype, N, 0, N, dG, x_slab, h_slab, partial, partial_bytes, n_cu, stream);
+  if (rc != NINT_OK) return rc;
+  return nint_conv_wgrad_finalize(ly, g, dtype, N, 1, 0, N, dG, dW, db, partial, n_cu, db_partial, db_rows, stream);
 }

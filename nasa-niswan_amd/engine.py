@@ -131,8 +131,9 @@ class SeqEngine:
             ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k = cfg.Cx, Cxp, cfg.Ch, Ch16, Chp, cfg.k
             ly.Wf, ly.Wd, ly.bias_p = self.Wf[-1].data_ptr(), self.Wd[-1].data_ptr(), self.bias_p[-1].data_ptr()
             self.layers.append(ly)
-            # one split-K workspace per layer (256-byte aligned) so their weight-gradient launches may overlap
-            wg_bytes += (self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256
+            # split-K workspaces: one per layer and time chunk (256-byte aligned), so that the weight-gradient
+            # launches of different layers / chunks may overlap with each other and with the rest of BPTT
+            wg_bytes += _lib.NINT_WGRAD_CHUNKS * ((self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256)
         self._wg_bytes = wg_bytes
         self._wg_partial = None
         self.pool: Dict[tuple, List[Workspace]] = {}
