@@ -169,9 +169,18 @@ def main():
         flops = 2.0 * B * Hp * Wp * k0 * k0 * (C + ch0) * 4 * ch0          # algorithmic, per launch
         achieved = flops / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch of this kernel from the committed PMC pass (not collected live: PMC needs
+        # rocprofv3 around the process); only quoted for the exact configuration it was measured on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = f"{args.workload}/{args.dtype}/B{B}/conv_igemm_fwd_layer0"
+            traffic = tj.get(key, {}).get("bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roof = {"kernel": "conv_igemm_kernel<LSTM epilogue> layer 0 (B images, one time step)", "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None, "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
+                "traffic": traffic, "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
 
     samples = world * B * args.steps
     value = samples / elapsed
