@@ -16,6 +16,7 @@
 // Each workgroup keeps its 64 x (16*NTC*taps) output block in accumulators for its whole pixel
 // range and writes ONE partial slab; a second kernel folds the slabs in fixed order
 // (bitwise reproducible, no float atomics) into the OIHW gradient.
+#include <stdlib.h>
 #include "nint_common.h"
 
 struct WgradArgs {
@@ -32,12 +33,15 @@ template <int DT> struct WgTile;
 template <> struct WgTile<NINT_BF16> { static constexpr int PR = 4, RA = 160; static constexpr int rb(int ntc) { return ntc == 1 ? 32 : 96; } };
 template <> struct WgTile<NINT_F32> { static constexpr int PR = 2, RA = 320; static constexpr int rb(int ntc) { return ntc == 1 ? 64 : 192; } };
 
-template <int DT, int JW>
+// NS = gate-column groups among the 4 waves: NS=1 -> every wave owns all 4 row tiles and a quarter of
+// the (tap, channel-tile) columns; NS=2 -> (2 row tiles) x (half of the columns): 25 taps split 13+12
+// instead of 7+7+7+4, at the price of more fragment reads per MFMA.
+template <int DT, int JW, int NS>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   typedef Elem<DT> E;
   typedef WgTile<DT> TT;
   constexpr int PR = TT::PR, RA = TT::RA;
-  constexpr int NTN = 4;
+  constexpr int NTN = 4 / NS;
   constexpr int A_UNITS_PIX = 64 * E::ES / 16;           // 16-byte units per dG pixel row (64 gate columns)
   constexpr int A_UNITS = PR * 32 * A_UNITS_PIX;
   constexpr int A_PER_THR = A_UNITS / 256;
@@ -58,7 +62,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const int nb = blockIdx.y / a.CB, cb = blockIdx.y % a.CB;
   const int t_begin = blockIdx.x * a.tiles_per_split;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
-  const int j0 = wave * JW;
+  const int i0 = (wave % NS) * NTN;           // first row tile (16 gate columns each) of this wave
+  const int j0 = (wave / NS) * JW;
 
   f32x4_t acc[NTN][JW];
 #pragma unroll
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         u32x4_t af[NTN];
 #pragma unroll
         for (int i = 0; i < NTN; ++i) {
-          const char* ad = Ab + apix0 * RA + i * 32 + p8;
+          const char* ad = Ab + apix0 * RA + (i0 + i) * 32 + p8;
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad));
           s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + 16 * RA));
           u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             float af[NTN];
 #pragma unroll
             for (int i = 0; i < NTN; ++i)
-              af[i] = *(const float*)(Ab + (pr * 32 + seg + 4 * m) * RA + (i * 16 + i16) * 4);
+              af[i] = *(const float*)(Ab + (pr * 32 + seg + 4 * m) * RA + ((i0 + i) * 16 + i16) * 4);
 #pragma unroll
             for (int jj = 0; jj < JW; ++jj) {
               const float bf = *(const float*)(Bb + boff[jj] + (pr * HWt + seg + 4 * m) * RB + i16 * 4);
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       for (int i = 0; i < NTN; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          out[(size_t)j * 1024 + (i * 16 + 4 * g + r) * 16 + i16] = acc[i][jj][r];
+          out[(size_t)j * 1024 + ((i0 + i) * 16 + 4 * g + r) * 16 + i16] = acc[i][jj][r];
     }
   }
 }
@@ -282,7 +287,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 
 // ------------------------------------------------------------------------------ host side
 struct WgPlan {
-  int NTC, J, JW, NB, CBx, CBh, splits_x, splits_h, tiles_x, tiles_y, ntiles, tps_x, tps_h;
+  int NTC, J, JW, NS, NB, CBx, CBh, splits_x, splits_h, tiles_x, tiles_y, ntiles, tps_x, tps_h;
   size_t off_h, off_db, total_floats;
   int db_rows;
 };
@@ -292,8 +297,11 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   if (ly->k != 1 && ly->k != 3 && ly->k != 5) return NINT_E_SHAPE;
   pl->NTC = (taps * 2 <= 20 && ly->Cxp % 32 == 0 && ly->Chp % 32 == 0) ? 2 : 1;
   pl->J = taps * pl->NTC;
-  pl->JW = pl->J <= 20 ? 5 : 7;
-  if (pl->J > 4 * pl->JW) return NINT_E_SHAPE;
+  // wave split: (NS row groups) x (4/NS column groups of JW columns); NINT_WG_NS=1|2 overrides
+  static const int ns_env = [] { const char* e = getenv("NINT_WG_NS"); return e ? atoi(e) : 0; }();
+  pl->NS = ns_env == 1 || ns_env == 2 ? ns_env : 1;   // NS=2 measured slower for 25 taps (register spills), equal for 9
+  if (pl->NS == 2) { pl->JW = (pl->J + 1) / 2; if (pl->JW > 13) return NINT_E_SHAPE; pl->JW = pl->JW <= 9 ? 9 : 13; }
+  else { pl->JW = pl->J <= 20 ? 5 : 7; if (pl->J > 4 * pl->JW) return NINT_E_SHAPE; }
   const int CW = 16 * pl->NTC;
   if (ly->Cxp % CW || ly->Chp % CW) return NINT_E_SHAPE;
   pl->NB = 4 * ly->Ch16 / 64;
@@ -336,7 +344,7 @@ extern "C" size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, in
   return pl.total_floats * sizeof(float);
 }
 
-template <int DT, int JW>
+template <int DT, int JW, int NS>
 static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   typedef WgTile<DT> TT;
   const int p = a.p;
@@ -346,7 +354,7 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   const int b_units = (TT::PR + 2 * p) * (32 + 2 * p) * (16 * a.NTC * Elem<DT>::ES / 16);
   if (b_units > 5 * 256) return NINT_E_SHAPE;
   if (lds > 160 * 1024) return NINT_E_LDS;
-  auto kern = wgrad_kernel<DT, JW>;
+  auto kern = wgrad_kernel<DT, JW, NS>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(splits, nblk), dim3(256), lds, st, a);
@@ -389,9 +397,11 @@ extern "C" int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g,
     const int splits = part == 0 ? pl.splits_x : pl.splits_h;
     const int nblk = pl.NB * a.CB;
     if (dtype == NINT_BF16)
-      rc = pl.JW == 5 ? launch_wgrad<NINT_BF16, 5>(a, splits, nblk, st) : launch_wgrad<NINT_BF16, 7>(a, splits, nblk, st);
+      rc = pl.NS == 2 ? (pl.JW == 9 ? launch_wgrad<NINT_BF16, 9, 2>(a, splits, nblk, st) : launch_wgrad<NINT_BF16, 13, 2>(a, splits, nblk, st))
+                      : (pl.JW == 5 ? launch_wgrad<NINT_BF16, 5, 1>(a, splits, nblk, st) : launch_wgrad<NINT_BF16, 7, 1>(a, splits, nblk, st));
     else
-      rc = pl.JW == 5 ? launch_wgrad<NINT_F32, 5>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 7>(a, splits, nblk, st);
+      rc = pl.NS == 2 ? (pl.JW == 9 ? launch_wgrad<NINT_F32, 9, 2>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 13, 2>(a, splits, nblk, st))
+                      : (pl.JW == 5 ? launch_wgrad<NINT_F32, 5, 1>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 7, 1>(a, splits, nblk, st));
     if (rc != NINT_OK) return rc;
   }
   return NINT_OK;
