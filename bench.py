@@ -31,6 +31,9 @@ WORKLOADS = {
     # name: (C_in, hidden, kernels, out_channels, T, Hp, Wp, halo, grid)
     "cfg1-20level": (62, (64, 32, 16), (5, 3, 3), 20, 12, 100, 154, (5, 5), (90, 144)),
     "cfg1-refpinned": (5, (64, 32, 16), (5, 3, 3), 1, 12, 100, 154, (5, 5), (90, 144)),
+    # BASELINE.json configs[3] / configs[4]: parity-test shapes, runnable here for sizing (not bench lines)
+    "cfg3-1deg-hidden128": (62, (128, 128, 128), (3, 3, 3), 20, 24, 190, 298, (5, 5), (180, 288)),
+    "cfg4-multitracer-40lev": (126, (64, 32, 16), (5, 3, 3), 200, 12, 100, 154, (5, 5), (90, 144)),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md

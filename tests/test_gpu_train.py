@@ -157,3 +157,25 @@ def test_inference_helpers_match_oracle(pkg):
     refp = O.convlstm_forward(Xp, params)[:, :, 5:95, 5:149].numpy() * ds.y_std + ds.y_mean
     np.testing.assert_allclose(sweep[3], refp, rtol=1e-4, atol=1e-3 * float(np.abs(refp).max()))
     assert not np.allclose(sweep[3], pds)
+
+
+def test_bf16_loss_trajectory_tracks_f32_over_20_steps(pkg):
+    """the bf16 path (bf16 storage, f32 accumulate, f32 master weights) must follow the
+    f32 path's loss trajectory: 20 Adam steps on the same batch, relative loss difference <= 2 % at every
+    step, and both must actually learn."""
+    from nasa_niswan_amd.trainer import FusedTrainer
+    from oracle import convlstm_oracle as O
+    params = O.synth_params(5, [16, 8, 8], [5, 3, 3], 3, seed=21)
+    X, y = O.synth_batch(4, 6, 5, 30, 38, (20, 28), seed=21)
+    Xd, yd = X.cuda(), y.cuda()
+    losses = {}
+    for dt in ("f32", "bf16"):
+        net = pkg.ConvLSTM(5, [16, 8, 8], [5, 3, 3], 3, compute_dtype=dt).cuda()
+        net.load_state_dict(params)
+        tr = FusedTrainer(net, lr=2e-3, betas=(0.5, 0.999), halo=(5, 5))
+        losses[dt] = [float(tr.step(Xd, yd)) for _ in range(20)]
+    rel = [abs(a - b) / abs(a) for a, b in zip(losses["f32"], losses["bf16"])]
+    print("  f32 :", " ".join(f"{v:.4f}" for v in losses["f32"][::4]))
+    print("  bf16:", " ".join(f"{v:.4f}" for v in losses["bf16"][::4]), f" max rel diff {max(rel):.2e}")
+    assert max(rel) <= 2e-2
+    assert losses["f32"][-1] < 0.97 * losses["f32"][0] and losses["bf16"][-1] < 0.97 * losses["bf16"][0]
