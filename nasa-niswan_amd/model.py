@@ -120,8 +120,18 @@ class _CellFn(torch.autograd.Function):
         return None, None, dx, dh0, dc0, dWs[0], (dbs[0] if ctx.has_bias else None)
 
 
+class _EngineOwner:
+    """Mixin: the per-device engines hold device workspaces and ctypes structures; they are rebuilt on
+    demand and must not travel with pickling / copy.deepcopy of the module."""
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engines"] = {}
+        return state
+
+
 # ------------------------------------------------------------------------------ modules
-class ConvLSTMCell(nn.Module):
+class ConvLSTMCell(_EngineOwner, nn.Module):
     """reference model.py:196-231"""
 
     def __init__(self, input_channels, hidden_channels, kernel_size, bias=True, *, compute_dtype="f32"):
@@ -154,7 +164,7 @@ class ConvLSTMCell(nn.Module):
         return _CellFn.apply(self, torch.is_grad_enabled(), x, h, c, self.conv.weight, self.conv.bias)
 
 
-class ConvLSTM(nn.Module):
+class ConvLSTM(_EngineOwner, nn.Module):
     """reference model.py:234-274"""
 
     def __init__(self, input_channels, hidden_channels, kernel_size, num_layers, *, out_channels=1,

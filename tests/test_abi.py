@@ -71,3 +71,51 @@ def test_product_refuses_cpu_tensors():
         net(torch.zeros(1, 2, 4, 8, 8))
     with pytest.raises(AssertionError):
         pkg.ConvLSTM(4, [8, 8], [3], 1)          # model.py:237
+
+
+def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    """Error convention of the boundary: int return codes, never an abort.  Argument
+    validation happens before any HIP call, so it can be exercised on a CPU-only machine."""
+    from nasa_niswan_amd import _lib
+    lib = _lib.load()
+    g = _lib.NintGeom()
+    assert lib.nint_geom_make(C.byref(g), 100, 154, 2) == 0
+    ly = _lib.NintLayer()
+    ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k = 5, 32, 64, 64, 64, 5
+    E_ARG, E_SHAPE, E_ALIGN = -1, -2, -4
+    assert lib.nint_cell_fwd(C.byref(ly), C.byref(g), 1, 8, None, None, None, None, None, None, None) == E_ARG
+    assert lib.nint_cell_fwd(C.byref(ly), C.byref(g), 7, 8, 16, None, None, 16, 16, None, None) == E_ARG      # bad dtype
+    assert lib.nint_cell_fwd(C.byref(ly), C.byref(g), 1, 8, 24, None, None, 16, 16, None, None) == E_ALIGN   # x slab not 16-B aligned
+    ly.k = 4
+    assert lib.nint_cell_fwd(C.byref(ly), C.byref(g), 1, 8, 16, None, None, 16, 16, None, None) == E_ARG      # even kernel (model.py:204)
+    ly.k = 7
+    assert lib.nint_cell_fwd(C.byref(ly), C.byref(g), 1, 8, 16, None, None, 16, 16, None, None) == E_ARG      # k/2 > physical halo
+    ly.k = 5
+    assert lib.nint_conv_dgrad(C.byref(ly), C.byref(g), 1, 8, None, None, None, None) == E_ARG
+    assert lib.nint_conv_dgrad(C.byref(ly), C.byref(g), 1, 8, 16, None, None, None) == 0                     # nothing to produce: no-op
+    assert lib.nint_cell_bwd_pointwise(C.byref(ly), C.byref(g), 1, 8, None, None, None, None, None, None, None, None) == E_ARG
+    assert lib.nint_adam_flat(None, None, None, None, 10, 1e-3, 0.5, 0.999, 1e-8, 1, 1.0, None) == E_ARG
+    assert lib.nint_adam_flat(16, 16, 16, 16, 10, 1e-3, 0.5, 0.999, 1e-8, 0, 1.0, None) == E_ARG             # step is 1-based
+    assert lib.nint_loss_mse_l1_crop(16, 16, None, 16, None, 2, 1, 10, 10, 5, 5, 8, 8, None) == E_ARG         # crop outside the grid
+    assert lib.nint_pack_btchw(16, 16, 2, 3, 5, 4, C.byref(g), 1, None) == E_ARG                              # Cp < C
+    assert lib.nint_preproc_fuse_pad(None, None, 0, None, None, None, 1, 5, 5, 13, 13, 0, None) == E_ARG
+    seq = _lib.NintSeq()
+    assert lib.nint_seq_fwd(C.byref(seq), None) == E_ARG                                                      # L = 0
+    assert lib.nint_seq_bwd(None, None) == E_ARG
+    for code in (E_ARG, E_SHAPE, -3, E_ALIGN):
+        assert lib.nint_error_string(code).decode().startswith("nint:")
+    with pytest.raises(_lib.NintError, match="shape not supported"):
+        _lib.check(E_SHAPE, "probe")
+
+
+def test_modules_pickle_and_deepcopy_without_their_engines():
+    import copy
+    import pickle
+    import torch
+    import nasa_niswan_amd as pkg
+    net = pkg.ConvLSTM(4, [8], [3], 1)
+    net._engines["fake"] = object()
+    twin = copy.deepcopy(net)
+    assert twin._engines == {} and torch.equal(twin.conv.weight, net.conv.weight)
+    again = pickle.loads(pickle.dumps(net))
+    assert again._engines == {} and list(again.state_dict()) == list(net.state_dict())
