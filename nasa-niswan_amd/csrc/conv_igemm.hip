@@ -7,17 +7,19 @@
 // GEMM view: M = pixels (16 consecutive x per MFMA row tile), N = output columns
 // (gate channels / cat channels), K = (64-byte channel chunk, tap).  The zero padding of
 // nn.Conv2d is physical: sources are halo slabs whose border is kept zero, so no tap is ever
-// predicated.  A workgroup (4 waves) owns 8 rows x 16 columns of pixels:
-//   - A: its (8+2p) x (16+2p) halo tile is staged in LDS, several channel chunks per fill, laid
+// predicated.  A workgroup (4 waves) owns MT (8 or 4) rows x 16 columns of pixels:
+//   - A: its (MT+2p) x (16+2p) halo tile is staged in LDS, several channel chunks per fill, laid
 //     out [chunk][g][halo pixel][16 B] (g = the lane group that consumes those 16 bytes), so
 //     every A fragment read is a lane-linear ds_read_b128 (no bank conflicts) and a tap is a
 //     constant address offset.  The image is read-only between fills: NO barrier in the K loop.
 //   - B: weights are pre-packed in MFMA fragment order, so a wave's B fragment is one fully
-//     coalesced 1 KiB global load straight into VGPRs (L2-resident, prefetched one K-step ahead).
+//     coalesced 1 KiB global load straight into VGPRs (L2-resident, 3-deep register ring).
 //     Waves never share B: the 4 waves split the work as WN column groups x WK K-slices, every
-//     wave computing 8 row tiles x NTW column tiles (24-32 MFMAs per 8 LDS reads).  K-slices are
-//     summed through LDS once at the end (narrow-N layers: layer 3, dgrad of layer 1).
-//   - the i,f,g,o tiles of one hidden channel sit in the same lane (column order
+//     wave computing MT row tiles x NTW column tiles.  K-slices (narrow-N launches) are summed
+//     through ONE LDS exchange at the end, after which every wave owns MT/WK rows of the epilogue.
+//   - operands are fed to the MFMA swapped (A := weights, B := pixels), so D = [channel][pixel]: a
+//     lane owns 4 consecutive channels of one pixel -> 16-byte / 8-byte vector epilogue; the
+//     i,f,g,o tiles of one hidden channel sit in the same lane (column order
 //     n' = (cblock*4+gate)*16+col), so the LSTM epilogue needs no cross-lane traffic.
 #include <stdlib.h>
 #include "nint_common.h"
