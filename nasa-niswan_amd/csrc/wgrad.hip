@@ -36,7 +36,10 @@ template <> struct WgTile<NINT_F32> { static constexpr int PR = 2, RA = 320; sta
 // NS = gate-column groups among the 4 waves: NS=1 -> every wave owns all 4 row tiles and a quarter of
 // the (tap, channel-tile) columns; NS=2 -> (2 row tiles) x (half of the columns): 25 taps split 13+12
 // instead of 7+7+7+4, at the price of more fragment reads per MFMA.
-template <int DT, int JW, int NS>
+// KS (kernel size) and NTCT (channel tiles per column block) are template parameters so that every LDS
+// fragment address is `per-lane base VGPR + compile-time immediate`: the transposed reads then cost no
+// VALU instruction at all (the MFMAs leave only ~8 issue cycles each to the rest of the wave).
+template <int DT, int JW, int NS, int KS, int NTCT>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   typedef Elem<DT> E;
   typedef WgTile<DT> TT;
@@ -50,14 +53,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p = a.p, k = a.k;
-  const int HWt = 32 + 2 * p, HHt = PR + 2 * p;
-  const int RB = TT::rb(a.NTC);
-  const int b_units_pix = 16 * a.NTC * E::ES / 16;       // units per cat halo pixel
-  const int b_units = HHt * HWt * b_units_pix;
-  const int a_bytes = PR * 32 * RA;
-  const int b_bytes = nint_round_up(HHt * HWt * RB, 16);
-  const int buf_bytes = a_bytes + b_bytes;
+  constexpr int p = KS / 2, k = KS;
+  constexpr int HWt = 32 + 2 * p, HHt = PR + 2 * p;
+  constexpr int RB = TT::rb(NTCT);
+  constexpr int b_units_pix = 16 * NTCT * E::ES / 16;    // units per cat halo pixel
+  constexpr int b_units = HHt * HWt * b_units_pix;
+  constexpr int a_bytes = PR * 32 * RA;
+  constexpr int b_bytes = (HHt * HWt * RB + 15) / 16 * 16;
+  constexpr int buf_bytes = a_bytes + b_bytes;
 
   const int nb = blockIdx.y / a.CB, cb = blockIdx.y % a.CB;
   const int t_begin = blockIdx.x * a.tiles_per_split;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       areg[i] = *(const u32x4_t*)(ga + ((long)py * a.Wh + px) * a.dG_pix_stride + q * 16);
     }
     const char* gb = a.src + (long)img * a.src_img_stride +
-                     ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride + cb * 16 * a.NTC * E::ES;
+                     ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride + cb * 16 * NTCT * E::ES;
 #pragma unroll
     for (int i = 0; i < B_PER_THR_MAX; ++i) {
       const int u = tid + i * 256;
@@ -126,43 +129,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 
   // lane constants of the transposed reads
   const int g = lane >> 4, i16 = lane & 15;
-  // per-wave constants: byte offset of each of this wave's (tap, channel tile) columns inside the
-  // cat halo image -- hoisted out of the tile loop (they cost two scalar divisions each)
-  int boff[JW];
+  // Per-lane base offsets (VGPRs, computed once).  Column jj of this wave is (tap, channel tile)
+  // j0+jj; columns past J are clamped duplicates whose accumulators are never flushed, which keeps
+  // the K loop branch-free.
+  int vB[JW];
+  int vA;
+  if constexpr (DT == NINT_BF16) {
+    const int q = i16 >> 2, p8 = (i16 & 3) * 8;
+    vA = (4 * g + q) * RA + i0 * 32 + p8;             // pixel 4g+q of a 16-pixel half segment, 8 bytes of 4 channels
 #pragma unroll
-  for (int jj = 0; jj < JW; ++jj) {
-    const int j = min(j0 + jj, a.J - 1);
-    const int tap = j / a.NTC, ct = j - tap * a.NTC;
-    const int tyy = tap / k, txx = tap - tyy * k;
-    boff[jj] = (tyy * HWt + txx) * RB + ct * 16 * E::ES;
+    for (int jj = 0; jj < JW; ++jj) {
+      const int j = min(j0 + jj, a.J - 1);
+      const int tap = j / NTCT, ct = j - tap * NTCT;
+      const int tyy = tap / k, txx = tap - tyy * k;
+      vB[jj] = a_bytes + (tyy * HWt + txx + 4 * g + q) * RB + ct * 32 + p8;
+    }
+  } else {
+    vA = g * RA + (i0 * 16 + i16) * 4;                // MFMA m of a 16-pixel K-step takes pixel 4m+g
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      const int j = min(j0 + jj, a.J - 1);
+      const int tap = j / NTCT, ct = j - tap * NTCT;
+      const int tyy = tap / k, txx = tap - tyy * k;
+      vB[jj] = a_bytes + (tyy * HWt + txx + g) * RB + (ct * 16 + i16) * 4;
+    }
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int cur = (tile - t_begin) & 1;
     const bool more = tile + 1 < t_end;
     if (more) issue_loads(tile + 1);
-    const char* Ab = smem + cur * buf_bytes;
-    const char* Bb = Ab + a_bytes;
+    const char* Ab = smem + cur * buf_bytes + vA;      // one add per base and tile; everything below is base + immediate
+    const char* Bb[JW];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) Bb[jj] = smem + cur * buf_bytes + vB[jj];
     if constexpr (DT == NINT_BF16) {
-      const int q = i16 >> 2, p8 = (i16 & 3) * 8;
-#pragma unroll 1
+#pragma unroll
       for (int pr = 0; pr < PR; ++pr) {
         // pixel -> K-slot: read rd covers pixels rd*16 + 4*g + q of the 32-pixel row segment
-        const int apix0 = pr * 32 + 4 * g + q;
         u32x4_t af[NTN];
 #pragma unroll
         for (int i = 0; i < NTN; ++i) {
-          const char* ad = Ab + apix0 * RA + (i0 + i) * 32 + p8;
+          const char* ad = Ab + pr * 32 * RA + i * 32;
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad));
           s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + 16 * RA));
           u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
           af[i] = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
         }
-        // branch-free: columns past J are clamped duplicates (boff) whose accumulators are never
-        // flushed, so all JW fragment reads of the K-step can be in flight ahead of its MFMAs
         u32x4_t bf[JW];
 #pragma unroll
         for (int jj = 0; jj < JW; ++jj) {
-          const char* bd = Bb + boff[jj] + (pr * HWt + 4 * g + q) * RB + p8;
+          const char* bd = Bb[jj] + pr * HWt * RB;
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd));
           s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd + 16 * RB));
           u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
@@ -174,21 +190,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
           for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
       }
     } else {
-#pragma unroll 1
+#pragma unroll
       for (int pr = 0; pr < PR; ++pr) {
-#pragma unroll 1
+#pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           // 16 pixels per K-step: MFMA m takes pixel 4*m + g of the segment as its K index g
-          const int seg = ks * 16 + g;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             float af[NTN];
 #pragma unroll
             for (int i = 0; i < NTN; ++i)
-              af[i] = *(const float*)(Ab + (pr * 32 + seg + 4 * m) * RA + ((i0 + i) * 16 + i16) * 4);
+              af[i] = *(const float*)(Ab + (pr * 32 + ks * 16 + 4 * m) * RA + i * 64);
 #pragma unroll
             for (int jj = 0; jj < JW; ++jj) {
-              const float bf = *(const float*)(Bb + boff[jj] + (pr * HWt + seg + 4 * m) * RB + i16 * 4);
+              const float bf = *(const float*)(Bb[jj] + (pr * HWt + ks * 16 + 4 * m) * RB);
 #pragma unroll
               for (int i = 0; i < NTN; ++i)
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
@@ -300,6 +315,7 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   // wave split: (NS row groups) x (4/NS column groups of JW columns); NINT_WG_NS=1|2 overrides
   static const int ns_env = [] { const char* e = getenv("NINT_WG_NS"); return e ? atoi(e) : 0; }();
   pl->NS = ns_env == 1 || ns_env == 2 ? ns_env : 1;   // NS=2 measured slower for 25 taps (register spills), equal for 9
+  if (pl->NS == 2 && ly->k == 1) pl->NS = 1;
   if (pl->NS == 2) { pl->JW = (pl->J + 1) / 2; if (pl->JW > 13) return NINT_E_SHAPE; pl->JW = pl->JW <= 9 ? 9 : 13; }
   else { pl->JW = pl->J <= 20 ? 5 : 7; if (pl->J > 4 * pl->JW) return NINT_E_SHAPE; }
   const int CW = 16 * pl->NTC;
@@ -344,7 +360,7 @@ extern "C" size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, in
   return pl.total_floats * sizeof(float);
 }
 
-template <int DT, int JW, int NS>
+template <int DT, int JW, int NS, int KS, int NTCT>
 static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   typedef WgTile<DT> TT;
   const int p = a.p;
@@ -354,12 +370,30 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   const int b_units = (TT::PR + 2 * p) * (32 + 2 * p) * (16 * a.NTC * Elem<DT>::ES / 16);
   if (b_units > 5 * 256) return NINT_E_SHAPE;
   if (lds > 160 * 1024) return NINT_E_LDS;
-  auto kern = wgrad_kernel<DT, JW, NS>;
+  if (a.k != KS || a.NTC != NTCT) return NINT_E_ARG;
+  auto kern = wgrad_kernel<DT, JW, NS, KS, NTCT>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(splits, nblk), dim3(256), lds, st, a);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
+}
+
+// instantiated (kernel size, channel tiles, columns per wave, wave split) combinations
+template <int DT>
+static int dispatch_wgrad(WgradArgs& a, const WgPlan& pl, int splits, int nblk, hipStream_t st) {
+  const int key = a.k * 1000 + a.NTC * 100 + pl.JW * 2 + (pl.NS - 1);
+  switch (key) {
+    case 5 * 1000 + 1 * 100 + 7 * 2 + 0: return launch_wgrad<DT, 7, 1, 5, 1>(a, splits, nblk, st);
+    case 5 * 1000 + 1 * 100 + 13 * 2 + 1: return launch_wgrad<DT, 13, 2, 5, 1>(a, splits, nblk, st);
+    case 3 * 1000 + 2 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 3, 2>(a, splits, nblk, st);
+    case 3 * 1000 + 2 * 100 + 9 * 2 + 1: return launch_wgrad<DT, 9, 2, 3, 2>(a, splits, nblk, st);
+    case 3 * 1000 + 1 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 3, 1>(a, splits, nblk, st);
+    case 3 * 1000 + 1 * 100 + 9 * 2 + 1: return launch_wgrad<DT, 9, 2, 3, 1>(a, splits, nblk, st);
+    case 1 * 1000 + 2 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 1, 2>(a, splits, nblk, st);
+    case 1 * 1000 + 1 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 1, 1>(a, splits, nblk, st);
+    default: return NINT_E_SHAPE;
+  }
 }
 
 // One chunk of a (possibly time-chunked) weight-gradient reduction: images [n_first, n_first+N) of the
@@ -396,12 +430,7 @@ extern "C" int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g,
     a.tiles_per_split = part == 0 ? pl.tps_x : pl.tps_h;
     const int splits = part == 0 ? pl.splits_x : pl.splits_h;
     const int nblk = pl.NB * a.CB;
-    if (dtype == NINT_BF16)
-      rc = pl.NS == 2 ? (pl.JW == 9 ? launch_wgrad<NINT_BF16, 9, 2>(a, splits, nblk, st) : launch_wgrad<NINT_BF16, 13, 2>(a, splits, nblk, st))
-                      : (pl.JW == 5 ? launch_wgrad<NINT_BF16, 5, 1>(a, splits, nblk, st) : launch_wgrad<NINT_BF16, 7, 1>(a, splits, nblk, st));
-    else
-      rc = pl.NS == 2 ? (pl.JW == 9 ? launch_wgrad<NINT_F32, 9, 2>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 13, 2>(a, splits, nblk, st))
-                      : (pl.JW == 5 ? launch_wgrad<NINT_F32, 5, 1>(a, splits, nblk, st) : launch_wgrad<NINT_F32, 7, 1>(a, splits, nblk, st));
+    rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, pl, splits, nblk, st) : dispatch_wgrad<NINT_F32>(a, pl, splits, nblk, st);
     if (rc != NINT_OK) return rc;
   }
   return NINT_OK;
