@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   // the K loop branch-free.
   int vB[JW];
   int vA;
+  const int nvalid = __builtin_amdgcn_readfirstlane(min(JW, max(0, a.J - j0)));   // real columns of this wave
   if constexpr (DT == NINT_BF16) {
     const int q = i16 >> 2, p8 = (i16 & 3) * 8;
     vA = (4 * g + q) * RA + i0 * 32 + p8;             // pixel 4g+q of a 16-pixel half segment, 8 bytes of 4 channels
@@ -184,10 +185,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
           u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
           bf[jj] = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
         }
+        // the reads above are unconditional (clamped columns); the MFMAs of a column past J are skipped by a
+        // wave-uniform branch so that the short wave (25 taps = 7+7+7+4) does not burn matrix-pipe time
 #pragma unroll
-        for (int jj = 0; jj < JW; ++jj)
+        for (int jj = 0; jj < JW; ++jj) {
+          if (jj < nvalid) {
 #pragma unroll
-          for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
+            for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
+          }
+        }
       }
     } else {
 #pragma unroll
@@ -204,9 +210,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int jj = 0; jj < JW; ++jj) {
               const float bf = *(const float*)(Bb[jj] + (pr * HWt + ks * 16 + 4 * m) * RB);
+              if (jj < nvalid) {
 #pragma unroll
-              for (int i = 0; i < NTN; ++i)
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
+                for (int i = 0; i < NTN; ++i)
+                  acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
+              }
             }
           }
         }
