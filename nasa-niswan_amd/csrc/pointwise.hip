@@ -373,10 +373,41 @@ extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g,
 
 // ------------------------------------------------------------------------------ 1x1 head
 // pred[n][o][y][x] = b[o] + sum_c w[o][c] * h[n][y][x][c]     (model.py:251,274)
+// One thread per pixel: the channel vector is read once (16-byte loads), the weights are wave-uniform
+// (scalar loads), and every output plane is written coalesced along x.  CHV = channels held in registers.
+template <int DT, int CHV>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp, int O,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ pred, int H, int W, int P, int Hh, int Wh) {
+  const size_t npix = (size_t)N * H * W;
+  const size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int x = pix % W;
+  size_t r = pix / W;
+  const int y = r % H;
+  const int n = r / H;
+  const size_t hb = ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp;
+  float hv[CHV];
+#pragma unroll
+  for (int c = 0; c < CHV; c += 4) {
+    const f32x4_t v = (c < Chp) ? load_vec4<DT>(h, hb + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    hv[c] = v[0]; hv[c + 1] = v[1]; hv[c + 2] = v[2]; hv[c + 3] = v[3];
+  }
+  float* out = pred + ((size_t)n * O * H + y) * W + x;
+  for (int o = 0; o < O; ++o) {
+    float acc = b ? b[o] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CHV; ++c)
+      if (c < Ch) acc += w[o * Ch + c] * hv[c];
+    out[(size_t)o * H * W] = acc;
+  }
+}
+
+// generic widths: one thread per output element
 template <int DT>
-__global__ void head_fwd_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp, int O,
-                                const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ pred,
-                                int H, int W, int P, int Hh, int Wh) {
+__global__ void head_fwd_wide_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp, int O,
+                                     const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ pred,
+                                     int H, int W, int P, int Hh, int Wh) {
   const size_t total = (size_t)N * O * H * W;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int x = i % W;
@@ -391,9 +422,33 @@ __global__ void head_fwd_kernel(const void* __restrict__ h, int n0, int N, int C
   }
 }
 
-// dh[n][y][x][c] = sum_o w[o][c] * dpred[n][o][y][x]; one thread per (pixel, padded channel)
-__global__ void head_bwd_dh_kernel(const float* __restrict__ w, const float* __restrict__ dpred, float* __restrict__ dh,
-                                   int N, int Ch, int Chp, int O, int H, int W) {
+// dh[n][y][x][c] = sum_o w[o][c] * dpred[n][o][y][x].  One thread per pixel (dpred planes read coalesced
+// along x, weights wave-uniform), the padded channel vector is written with 16-byte stores.
+template <int CHV>
+__global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restrict__ w, const float* __restrict__ dpred,
+                                                          float* __restrict__ dh, int N, int Ch, int Chp, int O, int H, int W) {
+  const size_t npix = (size_t)N * H * W;
+  const size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const size_t yx = pix % ((size_t)H * W);
+  const size_t n = pix / ((size_t)H * W);
+  float acc[CHV];
+#pragma unroll
+  for (int c = 0; c < CHV; ++c) acc[c] = 0.f;
+  const float* dp = dpred + n * O * (size_t)H * W + yx;
+  for (int o = 0; o < O; ++o) {
+    const float d = dp[(size_t)o * H * W];
+#pragma unroll
+    for (int c = 0; c < CHV; ++c)
+      if (c < Ch) acc[c] += w[o * Ch + c] * d;
+  }
+#pragma unroll
+  for (int c = 0; c < CHV; c += 4)
+    if (c < Chp) *(f32x4_t*)(dh + pix * Chp + c) = (f32x4_t){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+}
+
+__global__ void head_bwd_dh_wide_kernel(const float* __restrict__ w, const float* __restrict__ dpred, float* __restrict__ dh,
+                                        int N, int Ch, int Chp, int O, int H, int W) {
   const size_t total = (size_t)N * H * W * Chp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % Chp;
@@ -497,13 +552,21 @@ __global__ __launch_bounds__(512) void head_bwd_dw_tiled_kernel(const void* __re
   if ((int)threadIdx.x < nout) partial[(size_t)blockIdx.x * nout + threadIdx.x] = acc;
 }
 
+// block = 64 outputs x blockDim/64 lanes over the per-workgroup partials; fixed order
 __global__ void head_bwd_dw_final_kernel(const float* __restrict__ partial, int nblocks, int Ch, int O,
                                          float* __restrict__ dw, float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[1024];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, G = blockDim.x >> 6;
   const int nout = O * (Ch + 1);
-  if (i >= nout) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nout + i];
+  if (i < nout) {
+#pragma unroll 4
+    for (int b = sub; b < nblocks; b += G) s += partial[(size_t)b * nout + i];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub != 0 || i >= nout) return;
+  for (int q = 1; q < G; ++q) s += red[q * 64 + (threadIdx.x & 63)];
   const int o = i / (Ch + 1), c = i % (Ch + 1);
   if (c < Ch) dw[o * Ch + c] = s;
   else db[o] = s;
@@ -512,14 +575,20 @@ __global__ void head_bwd_dw_final_kernel(const float* __restrict__ partial, int 
 extern "C" int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
                              const float* b, float* pred, const nint_geom* g, int dtype, void* stream) {
   if (!h_slab || !w || !pred || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
-  const size_t total = (size_t)N * O * g->H * g->W;
+  if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
+  const size_t total = (size_t)N * O * g->H * g->W, npix = (size_t)N * g->H * g->W;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == NINT_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
-  else if (dtype == NINT_F32)
-    hipLaunchKernelGGL(head_fwd_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
-  else
-    return NINT_E_ARG;
+  const dim3 gp((unsigned)((npix + 255) / 256));
+  if (Chp <= 64 && Chp % 4 == 0) {
+    if (dtype == NINT_BF16 && Chp <= 32) hipLaunchKernelGGL((head_fwd_kernel<NINT_BF16, 32>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+    else if (dtype == NINT_BF16) hipLaunchKernelGGL((head_fwd_kernel<NINT_BF16, 64>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+    else if (Chp <= 32) hipLaunchKernelGGL((head_fwd_kernel<NINT_F32, 32>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+    else hipLaunchKernelGGL((head_fwd_kernel<NINT_F32, 64>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+  } else if (dtype == NINT_BF16) {
+    hipLaunchKernelGGL(head_fwd_wide_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+  } else {
+    hipLaunchKernelGGL(head_fwd_wide_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+  }
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
@@ -531,7 +600,14 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dh) {
-    hipLaunchKernelGGL(head_bwd_dh_kernel, grid1d((size_t)N * g->H * g->W * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    const size_t npix = (size_t)N * g->H * g->W;
+    const dim3 gp((unsigned)((npix + 255) / 256));
+    if (Chp <= 32 && Chp % 4 == 0)
+      hipLaunchKernelGGL(head_bwd_dh_kernel<32>, gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    else if (Chp <= 64 && Chp % 4 == 0)
+      hipLaunchKernelGGL(head_bwd_dh_kernel<64>, gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    else
+      hipLaunchKernelGGL(head_bwd_dh_wide_kernel, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
     NINT_LAUNCH_CHECK();
   }
   const int nout = O * (Ch + 1);
@@ -542,7 +618,7 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
     else
       hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_F32>, dim3(HEAD_DW_BLOCKS), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
     NINT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(nint_cdiv(nout, 256)), dim3(256), 0, st, scratch, HEAD_DW_BLOCKS, Ch, O, dw, db);
+    hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(nint_cdiv(nout, 64)), dim3(1024), 0, st, scratch, HEAD_DW_BLOCKS, Ch, O, dw, db);
     NINT_LAUNCH_CHECK();
   } else if (dw && db) {
     if (dtype == NINT_BF16)
@@ -595,15 +671,26 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
   if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-__global__ void loss_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ loss_out,
-                                  double* __restrict__ stats, double count) {
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ loss_out,
+                                                         double* __restrict__ stats, double count) {
+  // thread (b, q) = one partial; fixed-order tree over the blocks
+  __shared__ double red[4][256];
+  for (int q = 0; q < 4; ++q) {
+    double s = 0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[b * 4 + q];
+    red[q][threadIdx.x] = s;
+  }
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + st];
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    double s[4] = {0, 0, 0, 0};
-    for (int b = 0; b < nblocks; ++b)
-      for (int q = 0; q < 4; ++q) s[q] += partial[b * 4 + q];
-    if (loss_out) loss_out[0] = (float)(s[0] / count + s[1] / count);
+    const double s0 = red[0][0], s1 = red[1][0], s2 = red[2][0], s3 = red[3][0];
+    if (loss_out) loss_out[0] = (float)(s0 / count + s1 / count);
     if (stats) {
-      stats[0] += s[0]; stats[1] += s[1]; stats[2] += s[2]; stats[3] += s[3]; stats[4] += count;
+      stats[0] += s0; stats[1] += s1; stats[2] += s2; stats[3] += s3; stats[4] += count;
     }
   }
 }
@@ -620,7 +707,7 @@ extern "C" int nint_loss_mse_l1_crop(const float* pred, const float* y, float* d
   double* partial = (double*)(loss_out + 2);   // loss_out: [0]=loss, [1]=pad, [2..] = 256*4 doubles
   hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, pred, y, dpred, partial, N, O, H, W, oy, ox, Hc, Wc);
   NINT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, partial, LOSS_BLOCKS, loss_out, stats, (double)N * O * Hc * Wc);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, LOSS_BLOCKS, loss_out, stats, (double)N * O * Hc * Wc);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }

@@ -239,43 +239,58 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// Fold the split-K slabs of ONE source (x or h part) into dW (OIHW f32).  One thread per element of
-// the slab layout [block][j][n'loc 64][c 16] -> every split is read fully coalesced, in fixed order
-// (bitwise reproducible); only the single write per weight is scattered.
+// Fold the split-K slabs of ONE source (x or h part) into dW (OIHW f32).  A workgroup owns 64 consecutive
+// elements of the slab layout [block][j][n'loc 64][c 16] (one 256-byte line per split, fully coalesced) and
+// spreads the splits over its blockDim/64 waves; the per-wave sums are folded through LDS.  The order is a
+// fixed function of the launch shape (bitwise reproducible); only the single write per weight is scattered.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Cx, int Ch, int Ch16, int k,
                                     int NB, int CB, int NTC, int splits, int is_h, int nchunks, size_t chunk_stride) {
+  __shared__ float red[1024];
   const int taps = k * k, Ctot = Cx + Ch;
   const int J = taps * NTC;
   const size_t slab = (size_t)NB * CB * J * 1024;
-  const int Csrc = is_h ? Ch : Cx;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < slab; i += (size_t)gridDim.x * blockDim.x) {
-    const int c16 = i & 15, nloc = (i >> 4) & 63;
-    size_t r = i >> 10;
-    const int j = r % J; r /= J;
-    const int cb = r % CB;
-    const int nb = r / CB;
-    const int tap = j / NTC, ct = j - tap * NTC;
-    const int cc = (cb * NTC + ct) * 16 + c16;          // channel inside this source
-    const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
-    const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
-    if (cc >= Csrc || ch >= Ch) continue;               // padding rows / columns
-    float s = 0.f;
-    for (int ch_ = 0; ch_ < nchunks; ++ch_)
-      for (int sp = 0; sp < splits; ++sp) s += part[ch_ * chunk_stride + sp * slab + i];
-    const int ic = is_h ? Cx + cc : cc;
-    dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, G = blockDim.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;       // slab is a multiple of 1024: no tail
+  float s = 0.f;
+  for (int ch_ = 0; ch_ < nchunks; ++ch_) {
+    const float* src = part + ch_ * chunk_stride + i;
+#pragma unroll 4
+    for (int sp = grp; sp < splits; sp += G) s += src[(size_t)sp * slab];
   }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  for (int q = 1; q < G; ++q) s += red[q * 64 + lane];
+  const int c16 = i & 15, nloc = (i >> 4) & 63;
+  size_t r = i >> 10;
+  const int j = r % J; r /= J;
+  const int cb = r % CB;
+  const int nb = r / CB;
+  const int tap = j / NTC, ct = j - tap * NTC;
+  const int cc = (cb * NTC + ct) * 16 + c16;          // channel inside this source
+  const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
+  const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
+  const int Csrc = is_h ? Ch : Cx;
+  if (cc >= Csrc || ch >= Ch) return;                 // padding rows / columns
+  const int ic = is_h ? Cx + cc : cc;
+  dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
 }
 
-// column sums of a row-major f32 matrix [rows][Gc]: grid = (row splits, Gc/64); fixed order.
-__global__ __launch_bounds__(256) void rowsum_partial_kernel(const float* __restrict__ m, float* __restrict__ partial, int rows, int Gc) {
-  const int colgrp = blockIdx.y, col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+// column sums of a row-major f32 matrix [rows][ld] over columns [64*blockIdx.x, +64): block = 64 columns x
+// blockDim/64 row lanes, grid.y row groups; partial[blockIdx.y][ld].  Fixed order.
+__global__ void rowsum_partial_kernel(const float* __restrict__ m, float* __restrict__ partial, int rows, int ld) {
+  __shared__ float red[1024];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, G = blockDim.x >> 6;
   float acc = 0.f;
-  for (int r = blockIdx.x * 4 + sub; r < rows; r += gridDim.x * 4) acc += m[(size_t)r * Gc + colgrp * 64 + col];
-  __shared__ float red[256];
+  if (col < ld) {
+#pragma unroll 4
+    for (int r = blockIdx.y * G + sub; r < rows; r += gridDim.y * G) acc += m[(size_t)r * ld + col];
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
-  if (sub == 0) partial[((size_t)blockIdx.x * gridDim.y + colgrp) * 64 + col] = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
+  if (sub != 0 || col >= ld) return;
+  for (int q = 1; q < G; ++q) acc += red[q * 64 + (threadIdx.x & 63)];
+  partial[(size_t)blockIdx.y * ld + col] = acc;
 }
 
 // db[o] = sum over all pixels of dG[.,o]: grid = (row splits, column groups of 64); fixed order.
@@ -298,13 +313,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
   if (sub == 0) partial[((size_t)blockIdx.x * gridDim.y + colgrp) * 64 + col] = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
 }
 
+// db[o] = sum of the partial rows; block = 64 outputs x blockDim/64 row lanes
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ db, int Ch, int Gc, int nrows) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= 4 * Ch) return;
-  const int gate = o / Ch, ch = o % Ch;
-  const int np = (ch >> 4) * 64 + gate * 16 + (ch & 15);
+  __shared__ float red[1024];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, G = blockDim.x >> 6;
+  const bool ok = o < 4 * Ch;
   float s = 0.f;
-  for (int r = 0; r < nrows; ++r) s += partial[(size_t)r * Gc + np];
+  if (ok) {
+    const int gate = o / Ch, ch = o % Ch;
+    const int np = (ch >> 4) * 64 + gate * 16 + (ch & 15);
+#pragma unroll 4
+    for (int r = sub; r < nrows; r += G) s += partial[(size_t)r * Gc + np];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub != 0 || !ok) return;
+  for (int q = 1; q < G; ++q) s += red[q * 64 + (threadIdx.x & 63)];
   db[o] = s;
 }
 
@@ -459,25 +483,25 @@ extern "C" int nint_conv_wgrad_finalize(const nint_layer* ly, const nint_geom* g
   for (int part = 0; part < 2; ++part) {
     const int CB = part == 0 ? pl.CBx : pl.CBh;
     const size_t slab = (size_t)pl.NB * CB * pl.J * 1024;
-    size_t gsz = (slab + 255) / 256;
-    if (gsz > 4096) gsz = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, st, partial + (part == 0 ? 0 : pl.off_h), dW,
-                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, part == 0 ? pl.splits_x : pl.splits_h, part,
-                       nchunks, chunk_stride_floats);
+    const int splits = part == 0 ? pl.splits_x : pl.splits_h;
+    // few large slabs: 4 waves share the splits; many small slabs: 16 waves
+    const int threads = splits * nchunks >= 64 ? 1024 : 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(slab / 64)), dim3(threads), 0, st, partial + (part == 0 ? 0 : pl.off_h), dW,
+                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, splits, part, nchunks, chunk_stride_floats);
     NINT_LAUNCH_CHECK();
   }
   {
     float* dbp = partial + pl.off_db;          // (chunk 0's tail is the scratch of the bias fold)
     dim3 grid(pl.db_rows, Gc / 64);
     if (db_partial) {
-      hipLaunchKernelGGL(rowsum_partial_kernel, grid, dim3(256), 0, st, db_partial, dbp, db_rows, Gc);
+      hipLaunchKernelGGL(rowsum_partial_kernel, dim3(Gc / 64, pl.db_rows), dim3(1024), 0, st, db_partial, dbp, db_rows, Gc);
     } else if (dtype == NINT_BF16) {
       hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N_total, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
     } else {
       hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N_total, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
     }
     NINT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(nint_cdiv(4 * ly->Ch, 256)), dim3(256), 0, st, dbp, db, ly->Ch, Gc, pl.db_rows);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nint_cdiv(4 * ly->Ch, 64)), dim3(1024), 0, st, dbp, db, ly->Ch, Gc, pl.db_rows);
     NINT_LAUNCH_CHECK();
   }
   return NINT_OK;
