@@ -102,3 +102,42 @@ def test_full_size_properties(pkg):
     print(f"  bf16 vs f32 at full size: pred rel-L2 {r:.2e}, grads rel-L2 {rg:.2e}")
     assert r < 2e-2 and rg < 5e-2
     assert torch.isfinite(grads["f32"]).all()
+
+
+def heavy_tail_batch(B, T, H, W, seed=0):
+    """SURVEY.md section 8d stress inputs for the ref-pinned 5-channel stack [u, v, omega, prec, src]:
+    z-scored precipitation and emission are max(0, lognormal) fields scaled to the extremes of
+    variable_statistics.json (max z about 65 and 124); the target reaches z about 165."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((B, T, 5, H, W)).astype(np.float32)
+    for ch, zmax in ((3, 65.0), (4, 124.0)):
+        f = rng.lognormal(mean=0.0, sigma=1.5, size=(B, T, H, W))
+        X[:, :, ch] = (f / f.max() * zmax).astype(np.float32)
+    y = rng.lognormal(mean=0.0, sigma=1.5, size=(B, 1, H, W))
+    y = (y / y.max() * 165.0).astype(np.float32)
+    return torch.from_numpy(X), torch.from_numpy(y)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_heavy_tail_inputs(pkg, dtype):
+    """Forward, MSE+L1 loss and every gradient on heavy-tailed inputs (what bf16 storage has to survive)."""
+    from oracle import convlstm_oracle as O
+    C, hidden, ks, B, T, H, W = 5, [64, 32, 16], [5, 3, 3], 2, 3, 20, 36
+    params = O.synth_params(C, hidden, ks, 3, out_channels=1, seed=3)
+    X, y = heavy_tail_batch(B, T, H, W)
+    assert X[:, :, 4].max() > 100 and y.max() > 150
+    net = pkg.ConvLSTM(C, hidden, ks, 3, compute_dtype=dtype).cuda()
+    net.load_state_dict(params)
+    pred = net(X.cuda())
+    loss = torch.nn.functional.mse_loss(pred, y.cuda()) + torch.nn.functional.l1_loss(pred, y.cuda())
+    loss.backward()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    po = O.convlstm_forward(X, leaf)
+    lo = torch.nn.functional.mse_loss(po, y) + torch.nn.functional.l1_loss(po, y)
+    lo.backward()
+    assert torch.isfinite(pred).all()
+    res = {"pred": (pred.detach().cpu(), po.detach()), "loss": (loss.detach().cpu().reshape(1), lo.detach().reshape(1))}
+    for k, p in net.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        res["grad." + k] = (p.grad.cpu(), leaf[k].grad)
+    check(res, dtype)
