@@ -33,6 +33,32 @@ enum { EPI_LSTM = 0, EPI_DGRAD = 1 };
 #define NINT_BD 3
 #endif
 constexpr int BD = NINT_BD;   // depth of the per-wave weight-fragment ring
+#ifndef NINT_AG
+#define NINT_AG 2
+#endif
+#ifndef NINT_ABUF
+#define NINT_ABUF 2
+#endif
+
+#ifdef NINT_STAMP
+// Diagnostic build only (tools/clockprobe.py): per-workgroup phase stamps.  The values go to a buffer of
+// their own that no kernel reads; the shipped library is built without NINT_STAMP.
+#define NINT_STAMP_WGS 4096
+__device__ unsigned long long g_stamp[NINT_STAMP_WGS * 8];
+#define NINT_STAMP_AT(slot)                                                              \
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < NINT_STAMP_WGS) {                      \
+    g_stamp[blockIdx.x * 8 + 2 * (slot)] = __builtin_amdgcn_s_memtime();                 \
+    g_stamp[blockIdx.x * 8 + 2 * (slot) + 1] = __builtin_amdgcn_s_memrealtime();         \
+  }
+extern "C" int nint_debug_read_stamps(unsigned long long* host, int n_wgs) {
+  if (!host || n_wgs <= 0 || n_wgs > NINT_STAMP_WGS) return NINT_E_ARG;
+  NINT_CHECK_HIP(hipDeviceSynchronize());
+  NINT_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), (size_t)n_wgs * 8 * sizeof(unsigned long long)));
+  return NINT_OK;
+}
+#else
+#define NINT_STAMP_AT(slot)
+#endif
 
 template <int DT, int EPI, int WN, int WK, int NTW, int MT>
 __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvArgs a) {
@@ -45,6 +71,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
+  NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wk = wave / WN;
   int tile = blockIdx.x;
@@ -136,41 +163,111 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       }
     }
     __syncthreads();                           // image visible to all waves
-    int s = s_lo;
-    for (; s + BD <= s_hi; s += BD) {
+    if (c_begin == 0) { NINT_STAMP_AT(1) }
+    // MT >= 8 (two workgroups per CU): the A fragments are software-pipelined in groups of AG rows through
+    // two register groups -- while the AG*NTW MFMAs of one group run, the reads of the group after next
+    // are in flight -- so that a wave alone on its SIMD keeps the matrix pipe busy.  (Left to itself the
+    // compiler serialises read-wait-MFMA every two rows to save registers: 66 % MFMA occupancy for a lone
+    // wave, which is what a workgroup sees whenever its CU partner is in its fill or epilogue.)
+    // MT = 4 (three workgroups per CU, 168-register budget) keeps the plain loop.
+    constexpr int AG = MT >= 8 ? NINT_AG : 0;
+    if constexpr (AG > 0) {
+      constexpr int NG = MT / AG;              // row groups per K-step
+      constexpr int NBUF = NINT_ABUF;          // register groups; the reads run NBUF-1 groups ahead of the MFMAs
+      constexpr int LA = NBUF - 1;
+      static_assert(MT % AG == 0 && LA >= 1 && LA <= NG && (NG * BD) % NBUF == 0 && NG % NBUF % 1 == 0, "group rotation must close over the unrolled ring");
+      u32x4_t ax[NBUF * AG];
+#define NINT_A_BASE() ((int)(cl * chunk_bytes + (tyy * HWt + txx) * 16) + a_lane_off)
+      int va = NINT_A_BASE();                  // LDS byte offset of this step's fragment (row 0) for this lane
+      if (s_lo < s_hi) {
 #pragma unroll
-      for (int d = 0; d < BD; ++d) {
-        const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
-        u32x4_t af[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
-        Bn = (Bn < Blast) ? Bn + bstep : Blast;
-        if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+        for (int i = 0; i < LA * AG; ++i) ax[i] = *(const u32x4_t*)(smem + va + rowoff[i]);
       }
-    }
-    // remainder (< BD steps): ring slots 0.. already hold exactly these steps
+      int s = s_lo;
+      // K-step number D (static, position in the unrolled ring) on ring slot BQ; MORE = another step follows in
+      // this slice (else the look-ahead re-reads this step)
+#define NINT_K_STEP(BQ, MORE, D)                                                                           \
+      {                                                                                                    \
+        {                                      /* branch-free tap advance */                               \
+          const bool m_ = (MORE);                                                                          \
+          int nx_ = txx + 1, ny_ = tyy, nc_ = cl;                                                          \
+          const bool wx_ = nx_ == k;                                                                       \
+          nx_ = wx_ ? 0 : nx_; ny_ = wx_ ? ny_ + 1 : ny_;                                                  \
+          const bool wy_ = ny_ == k;                                                                       \
+          ny_ = wy_ ? 0 : ny_; nc_ = wy_ ? nc_ + 1 : nc_;                                                  \
+          txx = m_ ? nx_ : txx; tyy = m_ ? ny_ : tyy; cl = m_ ? nc_ : cl;                                  \
+        }                                                                                                  \
+        const int vn = NINT_A_BASE();          /* next step's base (this step's again at the slice end) */ \
+        _Pragma("unroll") for (int q = 0; q < NG; ++q) {                                                   \
+          const int g_ = NG * (D) + q;         /* group counter inside the unrolled ring */                \
+          const int ql = q + LA;               /* the group whose reads are issued now */                  \
+          const int base = ql < NG ? va : vn;                                                              \
+          const int row = AG * (ql % NG);                                                                  \
+          const int bl = ((g_ + LA) % NBUF) * AG, bm = (g_ % NBUF) * AG;                                   \
+          _Pragma("unroll") for (int r = 0; r < AG; ++r)                                                   \
+            ax[bl + r] = *(const u32x4_t*)(smem + base + rowoff[row + r]);                                 \
+          _Pragma("unroll") for (int r = 0; r < AG; ++r)                                                   \
+            _Pragma("unroll") for (int j = 0; j < NTW; ++j)                                                \
+              acc[AG * q + r][j] = mma_step<DT>(BQ[j], ax[bm + r], acc[AG * q + r][j]);                    \
+          __builtin_amdgcn_sched_group_barrier(0x100, AG, 0);                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, AG * NTW * (DT == NINT_BF16 ? 1 : 4), 0);            \
+        }                                                                                                  \
+        va = vn;                                                                                           \
+      }
+      for (; s + BD <= s_hi; s += BD) {
 #pragma unroll
-    for (int d = 0; d < BD - 1; ++d) {
-      if (s + d < s_hi) {
-        const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
-        u32x4_t af[MT];
+        for (int d = 0; d < BD; ++d) {
+          NINT_K_STEP(bq[d], d + 1 < BD || s + BD < s_hi, d)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
+          for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
+          Bn = (Bn < Blast) ? Bn + bstep : Blast;
+        }
+      }
+      // remainder (< BD steps): ring slots 0.. already hold exactly these steps
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+      for (int d = 0; d < BD - 1; ++d) {
+        if (s + d < s_hi) NINT_K_STEP(bq[d], s + d + 1 < s_hi, d)
+      }
+#undef NINT_K_STEP
+#undef NINT_A_BASE
+    } else {
+  int s = s_lo;
+      for (; s + BD <= s_hi; s += BD) {
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
-        if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+        for (int d = 0; d < BD; ++d) {
+          const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
+          u32x4_t af[MT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
+          Bn = (Bn < Blast) ? Bn + bstep : Blast;
+          if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+        }
+      }
+      // remainder (< BD steps): ring slots 0.. already hold exactly these steps
+#pragma unroll
+      for (int d = 0; d < BD - 1; ++d) {
+        if (s + d < s_hi) {
+          const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
+          u32x4_t af[MT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
+          if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+        }
       }
     }
   }
 
+  NINT_STAMP_AT(2)
   // ------------------------------------------------------------------ K-slice reduction
   // Every wave OWNS Q = MT/WK of the rows: its local accumulators 0..Q-1 (local row ii of slice
   // wk is tile row (ii + wk*Q) % MT, see rowoff above), so the epilogue is spread over all four
@@ -267,6 +364,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       }
     }
   }
+  NINT_STAMP_AT(3)
 }
 
 // ------------------------------------------------------------------------------ host side
