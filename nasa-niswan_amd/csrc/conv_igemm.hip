@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   int rowoff[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) rowoff[i] = ((i + wk * Q) % MT) * HWt * 16;
-  const char* Bwave = a.Bp + (size_t)nt0 * 1024 + lane * 16;
+  const char* Bwave = a.Bp + (size_t)nt0 * 1024;   // wave-uniform (scalar) base; the lane part is a 32-bit offset
+  const unsigned blane = lane * 16;
   const size_t bstep = (size_t)a.NTt * 1024;   // bytes between consecutive K-steps in Bp
 
   for (int c_begin = 0; c_begin < nchunks; c_begin += a.cpf) {
@@ -152,14 +153,15 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
     // slice's last step) so that the compiler can count outstanding loads and emits
     // s_waitcnt vmcnt((BD-1)*NTW) instead of draining the ring with vmcnt(0) at every step.
     u32x4_t bq[BD][NTW];
-    const char* Blast = Bs + (size_t)(s_hi - 1 - s_lo) * bstep;     // last step of this slice
-    const char* Bn = Bs;                                            // next step to load
+    int b_rem = s_hi - 1 - s_lo;                                    // steps the load pointer may still advance
+    const char* Bn = Bs;                                            // next step to load (wave-uniform)
+#define NINT_B_ADVANCE() { const bool adv_ = b_rem > 0; b_rem -= adv_ ? 1 : 0; Bn += adv_ ? bstep : 0; }
     if (s_lo < s_hi) {
 #pragma unroll
       for (int d = 0; d < BD; ++d) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
-        Bn = (Bn < Blast) ? Bn + bstep : Blast;
+        for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + blane + j * 1024);
+        NINT_B_ADVANCE()
       }
     }
     __syncthreads();                           // image visible to all waves
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       constexpr int LA = NBUF - 1;
       static_assert(MT % AG == 0 && LA >= 1 && LA <= NG && (NG * BD) % NBUF == 0 && NG % NBUF % 1 == 0, "group rotation must close over the unrolled ring");
       u32x4_t ax[NBUF * AG];
-#define NINT_A_BASE() ((int)(cl * chunk_bytes + (tyy * HWt + txx) * 16) + a_lane_off)
-      int va = NINT_A_BASE();                  // LDS byte offset of this step's fragment (row 0) for this lane
+      int va = (int)(cl * chunk_bytes + (tyy * HWt + txx) * 16) + a_lane_off;   // LDS byte offset of this step's fragment (row 0)
+      const int d_row = (HWt - (k - 1)) * 16;                                  // tap (ty, k-1) -> (ty+1, 0)
+      const int d_chunk = chunk_bytes - ((k - 1) * HWt + (k - 1)) * 16;        // tap (k-1, k-1) -> next chunk, tap (0, 0)
       if (s_lo < s_hi) {
 #pragma unroll
         for (int i = 0; i < LA * AG; ++i) ax[i] = *(const u32x4_t*)(smem + va + rowoff[i]);
@@ -188,16 +191,14 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       // this slice (else the look-ahead re-reads this step)
 #define NINT_K_STEP(BQ, MORE, D)                                                                           \
       {                                                                                                    \
-        {                                      /* branch-free tap advance */                               \
-          const bool m_ = (MORE);                                                                          \
-          int nx_ = txx + 1, ny_ = tyy, nc_ = cl;                                                          \
-          const bool wx_ = nx_ == k;                                                                       \
-          nx_ = wx_ ? 0 : nx_; ny_ = wx_ ? ny_ + 1 : ny_;                                                  \
-          const bool wy_ = ny_ == k;                                                                       \
-          ny_ = wy_ ? 0 : ny_; nc_ = wy_ ? nc_ + 1 : nc_;                                                  \
-          txx = m_ ? nx_ : txx; tyy = m_ ? ny_ : tyy; cl = m_ ? nc_ : cl;                                  \
-        }                                                                                                  \
-        const int vn = NINT_A_BASE();          /* next step's base (this step's again at the slice end) */ \
+        /* branch-free tap advance: the next step's base is this one plus one of three constants */       \
+        const bool m_ = (MORE);                                                                            \
+        const bool wx_ = txx + 1 == k;                                                                     \
+        const bool wy_ = wx_ && (tyy + 1 == k);                                                            \
+        const int dl_ = wy_ ? d_chunk : (wx_ ? d_row : 16);                                                \
+        const int vn = va + (m_ ? dl_ : 0);    /* (this step's again at the slice end) */                  \
+        tyy = m_ ? (wy_ ? 0 : (wx_ ? tyy + 1 : tyy)) : tyy;                                                \
+        txx = m_ ? (wx_ ? 0 : txx + 1) : txx;                                                              \
         _Pragma("unroll") for (int q = 0; q < NG; ++q) {                                                   \
           const int g_ = NG * (D) + q;         /* group counter inside the unrolled ring */                \
           const int ql = q + LA;               /* the group whose reads are issued now */                  \
@@ -219,8 +220,9 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
         for (int d = 0; d < BD; ++d) {
           NINT_K_STEP(bq[d], d + 1 < BD || s + BD < s_hi, d)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
-          Bn = (Bn < Blast) ? Bn + bstep : Blast;
+          for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + blane + j * 1024);
+          NINT_B_ADVANCE()
+          __builtin_amdgcn_sched_group_barrier(0x020, NTW, 0);   // this slot's reloads go out before the next step starts
         }
       }
       // remainder (< BD steps): ring slots 0.. already hold exactly these steps
@@ -229,7 +231,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
         if (s + d < s_hi) NINT_K_STEP(bq[d], s + d + 1 < s_hi, d)
       }
 #undef NINT_K_STEP
-#undef NINT_A_BASE
     } else {
   int s = s_lo;
       for (; s + BD <= s_hi; s += BD) {
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
 #pragma unroll
             for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + j * 1024);
-          Bn = (Bn < Blast) ? Bn + bstep : Blast;
+          for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + blane + j * 1024);
+          NINT_B_ADVANCE()
           if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
         }
       }
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
     }
   }
 
+#undef NINT_B_ADVANCE
   NINT_STAMP_AT(2)
   // ------------------------------------------------------------------ K-slice reduction
   // Every wave OWNS Q = MT/WK of the rows: its local accumulators 0..Q-1 (local row ii of slice
