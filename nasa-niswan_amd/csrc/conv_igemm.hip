@@ -74,7 +74,14 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wk = wave / WN;
-  int tile = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
+  // with its own L2, so XCD x takes the CONTIGUOUS tile range x: neighbouring tiles (which share halo
+  // pixels) and, at B = 8, whole images then stay inside one L2.  Any bijection is correct.
+  int tile;
+  {
+    const int nb = gridDim.x, b = blockIdx.x, q8 = nb / 8, r8 = nb % 8, x = b % 8, i = b / 8;
+    tile = x * q8 + (x < r8 ? x : r8) + i;     // ranges of q8 (+1 for the first r8 XCDs) tiles
+  }
   const int tx = tile % a.tiles_x; tile /= a.tiles_x;
   const int ty = tile % a.tiles_y;
   const int img = tile / a.tiles_y;
