@@ -76,32 +76,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 
   u32x4_t areg[A_PER_THR], breg[B_PER_THR_MAX];
 
-  auto issue_loads = [&](int tile) {
-    const int tx = tile % a.tiles_x;
-    const int r = tile / a.tiles_x;
-    const int ty = r % a.tiles_y;
-    const int img = r / a.tiles_y;
-    const int y0 = ty * PR, x0 = tx * 32;
-    const char* ga = a.dG + (long)img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride +
-                     nb * 64 * E::ES;
+  // Staging addresses = wave-uniform tile base (SGPRs, advanced incrementally from tile to tile) + a per-thread
+  // 32-bit offset that does not depend on the tile (computed once): the tile loop spends no VALU and no
+  // integer division on addresses -- the loop is instruction-issue-bound, every instruction beside the MFMAs counts.
+  unsigned aoff[A_PER_THR], boff[B_PER_THR_MAX];
 #pragma unroll
-    for (int i = 0; i < A_PER_THR; ++i) {
-      const int u = tid + i * 256;
-      const int q = u % A_UNITS_PIX, pix = u / A_UNITS_PIX;
-      const int py = pix >> 5, px = pix & 31;
-      areg[i] = *(const u32x4_t*)(ga + ((long)py * a.Wh + px) * a.dG_pix_stride + q * 16);
-    }
-    const char* gb = a.src + (long)img * a.src_img_stride +
-                     ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride + cb * 16 * NTCT * E::ES;
+  for (int i = 0; i < A_PER_THR; ++i) {
+    const int u = tid + i * 256;
+    const int q = u % A_UNITS_PIX, pix = u / A_UNITS_PIX;
+    aoff[i] = (unsigned)(((pix >> 5) * a.Wh + (pix & 31)) * a.dG_pix_stride + q * 16);
+  }
 #pragma unroll
-    for (int i = 0; i < B_PER_THR_MAX; ++i) {
-      const int u = tid + i * 256;
-      if (u < b_units) {
-        const int q = u % b_units_pix, hp = u / b_units_pix;
-        const int hy = hp / HWt, hx = hp - hy * HWt;
-        breg[i] = *(const u32x4_t*)(gb + ((long)hy * a.Wh + hx) * a.src_pix_stride + q * 16);
-      }
-    }
+  for (int i = 0; i < B_PER_THR_MAX; ++i) {
+    const int u = min(tid + i * 256, b_units - 1);        // threads past the image re-read its last unit (never written to LDS)
+    const int q = u % b_units_pix, hp = u / b_units_pix;
+    const int hy = hp / HWt, hx = hp - hy * HWt;
+    boff[i] = (unsigned)((hy * a.Wh + hx) * a.src_pix_stride + q * 16);
+  }
+  // tile coordinates of the next tile to load, kept incrementally (tiles of a split are consecutive)
+  int ld_tx, ld_ty, ld_img;
+  {
+    const int r = t_begin / a.tiles_x;
+    ld_tx = t_begin - r * a.tiles_x;
+    ld_img = r / a.tiles_y;
+    ld_ty = r - ld_img * a.tiles_y;
+  }
+  const char* const ga0 = a.dG + nb * 64 * E::ES;
+  const char* const gb0 = a.src + cb * 16 * NTCT * E::ES;
+
+  auto issue_loads = [&]() {                 // loads tile (ld_img, ld_ty, ld_tx), then steps to the next one
+    const int y0 = ld_ty * PR, x0 = ld_tx * 32;
+    const char* ga = ga0 + (long)ld_img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride;
+#pragma unroll
+    for (int i = 0; i < A_PER_THR; ++i) areg[i] = *(const u32x4_t*)(ga + aoff[i]);
+    const char* gb = gb0 + (long)ld_img * a.src_img_stride + ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride;
+#pragma unroll
+    for (int i = 0; i < B_PER_THR_MAX; ++i)
+      if (i * 256 < b_units) breg[i] = *(const u32x4_t*)(gb + boff[i]);
+    const bool wx = ld_tx + 1 == a.tiles_x;
+    const bool wy = wx && (ld_ty + 1 == a.tiles_y);
+    ld_tx = wx ? 0 : ld_tx + 1;
+    ld_ty = wy ? 0 : (wx ? ld_ty + 1 : ld_ty);
+    ld_img += wy ? 1 : 0;
   };
   auto write_lds = [&](char* buf) {
 #pragma unroll
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < B_PER_THR_MAX; ++i) {
       const int u = tid + i * 256;
-      if (u < b_units) {
+      if (i * 256 < b_units && u < b_units) {
         const int q = u % b_units_pix, hp = u / b_units_pix;
         *(u32x4_t*)(bb + hp * RB + q * 16) = breg[i];
       }
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   };
 
   if (t_begin < t_end) {
-    issue_loads(t_begin);
+    issue_loads();
     write_lds(smem);
   }
   __syncthreads();
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int cur = (tile - t_begin) & 1;
     const bool more = tile + 1 < t_end;
-    if (more) issue_loads(tile + 1);
+    if (more) issue_loads();
     const char* Ab = smem + cur * buf_bytes + vA;      // one add per base and tile; everything below is base + immediate
     const char* Bb[JW];
 #pragma unroll
