@@ -190,3 +190,20 @@ def test_bf16_tracks_f32_along_a_training_trajectory(pkg):
         last = loss_f
     print(f"  20 steps: loss {first:.4f} -> {last:.4f}; worst |dloss|/loss {worst_loss:.2e}; worst grad cosine {worst_cos:.5f}")
     assert worst_loss <= 1e-2 and worst_cos >= 0.995 and last < 0.97 * first
+
+
+@pytest.mark.parametrize("env", [{"NINT_STREAMS": "1", "NINT_WG_CHUNKS": "2"}, {"NINT_MT": "4"}, {"NINT_MT": "8"}],
+                         ids=["layer-wavefront+chunked-wgrad", "all-4-row-tiles", "all-8-row-tiles"])
+def test_opt_in_schedules_and_tile_heights_keep_parity(pkg, env):
+    """The launch-shape switches are read once per process, so the model-level parity tests are
+    re-run in a child process under each setting: multi-stream layer wavefront with time-chunked weight
+    gradients, and both tile heights forced for every layer."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "model_forward_backward or input_gradient or cell_forward_backward"],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--C", type=int, default=62)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--H", type=int, default=100)
+    ap.add_argument("--W", type=int, default=154)
+    ap.add_argument("--split", type=int, default=1, help="issue the forward gate kernel as this many launches over image groups")
     args = ap.parse_args()
     lib = pkg.load_library()
     hidden, ks = (64, 32, 16), (5, 3, 3)
@@ -39,7 +42,7 @@ def main():
     for ch, k in zip(hidden, ks):
         cfgs.append(LayerCfg(cin, ch, k)); cin = ch
     eng = SeqEngine(cfgs, args.dtype, "cuda")
-    B, T, H, W = args.batch, args.T, 100, 154
+    B, T, H, W = args.batch, args.T, args.H, args.W
     ws = eng.acquire(B, T, H, W, True, False)
     ws_w = [torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * 0.05 for c in cfgs]
     ws_b = [torch.zeros(4 * c.Ch, device="cuda") for c in cfgs]
@@ -72,9 +75,16 @@ def main():
         fl = 2.0 * B * H * W * cfg.k ** 2 * (cfg.Cx + cfg.Ch) * 4 * cfg.Ch
 
         def fwd(ly=ly, xs=xs, hs=hs, cs=cs, gs=gs, l=l):
-            assert lib.nint_cell_fwd(C.byref(ly), g, eng.dt, B, C.c_void_p(xs), C.c_void_p(ws.h[l].data_ptr() + hs),
-                                     C.c_void_p(ws.c[l].data_ptr() + cs), C.c_void_p(ws.h[l].data_ptr() + 2 * hs),
-                                     C.c_void_p(ws.c[l].data_ptr() + 2 * cs), C.c_void_p(ws.gates[l].data_ptr() + gs), st) == 0
+            nb = B // args.split
+            for part in range(args.split):      # image groups: every slab pointer advances by the group's images
+                f = part * nb
+                assert lib.nint_cell_fwd(C.byref(ly), g, eng.dt, nb if part < args.split - 1 else B - f,
+                                         C.c_void_p(xs + f * (xs_img := halo_px * ly.Cxp * es)),
+                                         C.c_void_p(ws.h[l].data_ptr() + hs + f * halo_px * ly.Chp * es),
+                                         C.c_void_p(ws.c[l].data_ptr() + cs + f * comp_px * ly.Chp * 4),
+                                         C.c_void_p(ws.h[l].data_ptr() + 2 * hs + f * halo_px * ly.Chp * es),
+                                         C.c_void_p(ws.c[l].data_ptr() + 2 * cs + f * comp_px * ly.Chp * 4),
+                                         C.c_void_p(ws.gates[l].data_ptr() + gs + f * comp_px * 4 * ly.Ch16 * es), st) == 0
         run(f"fwd{l}", fwd, fl)
 
         def pw(ly=ly, cs=cs, gs=gs, dgs=dgs, l=l):
