@@ -125,3 +125,23 @@ def test_fused_adam_state_dict_is_torch_adam_format(tmp_path):
     ref3 = torch.optim.Adam(_tiny().parameters(), lr=1e-3)
     ref3.load_state_dict(opt.state_dict())
     assert float(ref3.state_dict()["state"][0]["step"]) == 2.0
+
+
+def test_module_tree_matches_reference_state_dict():
+    """parameter names, shapes and count of the reference stack
+    (model.py:197-251; 580,305 parameters, test.ipynb:4698-4699); AssertionError of model.py:237."""
+    import pytest
+    import nasa_niswan_amd as pkg
+    net = pkg.ConvLSTM(5, [64, 32, 16], [5, 3, 3], 3)
+    sd = net.state_dict()
+    want = {"layers.0.conv.weight": (256, 69, 5, 5), "layers.0.conv.bias": (256,),
+            "layers.1.conv.weight": (128, 96, 3, 3), "layers.1.conv.bias": (128,),
+            "layers.2.conv.weight": (64, 48, 3, 3), "layers.2.conv.bias": (64,),
+            "conv.weight": (1, 16, 1, 1), "conv.bias": (1,)}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    assert sum(p.numel() for p in net.parameters()) == 580305
+    cell = net.layers[0]
+    for attr in ("input_channels", "hidden_channels", "kernel_size", "padding", "bias", "conv", "sigmoid", "tanh"):
+        assert hasattr(cell, attr), attr
+    with pytest.raises(AssertionError):
+        pkg.ConvLSTM(5, [64, 32], [5, 3, 3], 3)
