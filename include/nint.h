@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 101
+#define NINT_VERSION 102
 #define NINT_DB_ROWS 1024   /* rows of bias-gradient partials one fused pointwise-backward launch writes */
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
@@ -73,7 +73,8 @@ typedef struct nint_seq {
   int32_t need_dx;          /* backward also produces d/dx of the input sequence */
   int32_t has_init_state;   /* 0: h0=c0=0 (reference ConvLSTM, model.py:259-262); 1: h[l][0], c0[l] given */
   int32_t n_cu;             /* CU count used to size split-K grids */
-  int32_t reserved;
+  int32_t zero_dstate;      /* backward: bit 2l = dc[l] is all-zero at entry, bit 2l+1 = dh[l] is all-zero at entry -- the first
+                             * BPTT step then neither reads nor needs them zero-filled (reference: zero state grads) */
   nint_geom g;
   nint_layer layer[NINT_MAX_LAYERS];
   const void* xs;                      /* ET halo slab [T*B][Hh][Wh][Cxp0]: packed input sequence */

@@ -31,7 +31,7 @@ class NintLayer(C.Structure):
 
 class NintSeq(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32),
-                ("need_dx", C.c_int32), ("has_init_state", C.c_int32), ("n_cu", C.c_int32), ("reserved", C.c_int32),
+                ("need_dx", C.c_int32), ("has_init_state", C.c_int32), ("n_cu", C.c_int32), ("zero_dstate", C.c_int32),
                 ("g", NintGeom), ("layer", NintLayer * NINT_MAX_LAYERS),
                 ("xs", vp), ("h", vp * NINT_MAX_LAYERS), ("c", vp * NINT_MAX_LAYERS),
                 ("gates", vp * NINT_MAX_LAYERS), ("dG", vp * NINT_MAX_LAYERS), ("dh", vp * NINT_MAX_LAYERS),
@@ -92,7 +92,7 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nint_version() != 101:
+    if lib.nint_version() != 102:
         raise NintError("libnint_hip.so version mismatch")
     _lib = lib
     return lib

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
           if (n < a.C0p) {
             if (a.out0) {
               f32x4_t* d = (f32x4_t*)(a.out0 + pix * a.C0p + n);
-              *d = *d + acc[i][j];
+              *d = a.out0_overwrite ? acc[i][j] : *d + acc[i][j];
             }
           } else if (a.out1) {
             *(f32x4_t*)(a.out1 + pix * a.C1p + (n - a.C0p)) = acc[i][j];
@@ -467,6 +467,11 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
 
 extern "C" int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                                const void* dG, float* dx_accum, float* dh_prev, void* stream) {
+  return nint_internal_conv_dgrad(ly, g, dtype, N, dG, dx_accum, dh_prev, false, stream);
+}
+
+int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, float* dx_accum,
+                             float* dh_prev, bool overwrite_dx, void* stream) {
   if (!ly || !g || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!dx_accum && !dh_prev) return NINT_OK;
@@ -485,6 +490,7 @@ extern "C" int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dty
   a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
   a.H = g->H; a.W = g->W; a.P = g->P; a.Hh = g->Hh; a.Wh = g->Wh;
   a.out0 = dx_accum; a.out1 = dh_prev;
+  a.out0_overwrite = overwrite_dx ? 1 : 0;
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
   // only the n-tiles whose destination exists are computed
   const int nt_x = ly->Cxp / 16, nt_h = ly->Chp / 16;

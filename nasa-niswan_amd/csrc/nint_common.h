@@ -122,4 +122,12 @@ struct ConvArgs {
   float* out0;           // += columns [0, C0p)
   float* out1;           // =  columns [C0p, C0p+C1p)
   int C0p, C1p;
+  int out0_overwrite;    // 1: columns [0, C0p) are stored, not accumulated (the destination is known to be zero)
 };
+
+// internal entry points shared between translation units (not part of the C ABI)
+int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
+                                     const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
+                                     float* db_partial, bool dc_zero, void* stream);
+int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, float* dx_accum,
+                             float* dh_prev, bool overwrite_dx, void* stream);

@@ -287,7 +287,7 @@ template <int DT, bool FUSE_DB>
 __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
                                           const float* __restrict__ c_new, const float* __restrict__ dh,
                                           float* __restrict__ dc, void* __restrict__ dG, float* __restrict__ db_partial,
-                                          int N, int H, int W, int P, int Hh, int Wh, int Ch16, int Chp) {
+                                          int N, int H, int W, int P, int Hh, int Wh, int Ch16, int Chp, int dc_zero) {
   const int nq = Ch16 >> 2;
   const size_t total = (size_t)N * H * W * nq;
   const int Gc = 4 * Ch16;
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __r
     if (c_prev) cp = *(const f32x4_t*)(c_prev + ci);
     const f32x4_t cn = *(const f32x4_t*)(c_new + ci);
     const f32x4_t dhv = *(const f32x4_t*)(dh + ci);
-    const f32x4_t dcv = *(const f32x4_t*)(dc + ci);
+    f32x4_t dcv = {0.f, 0.f, 0.f, 0.f};
+    if (!dc_zero) dcv = *(const f32x4_t*)(dc + ci);
     f32x4_t o_i, o_f, o_g, o_o, dcp;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -351,9 +352,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __r
   }
 }
 
-extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
-                                       const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
-                                       float* db_partial, void* stream) {
+int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
+                                     const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
+                                     float* db_partial, bool dc_zero, void* stream) {
   if (!ly || !g || !gates || !c_new || !dh || !dc || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   const int nq = ly->Ch16 / 4;
@@ -363,12 +364,18 @@ extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g,
   // a fused launch always has exactly NINT_DB_ROWS blocks (idle blocks write zero rows)
   const dim3 grid = db_partial ? dim3(NINT_DB_ROWS) : grid1d(total);
 #define NINT_PW(DT_, F_) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<DT_, F_>), grid, dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, \
-                                            db_partial, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp)
+                                            db_partial, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp, dc_zero ? 1 : 0)
   if (dtype == NINT_BF16) { if (db_partial) NINT_PW(NINT_BF16, true); else NINT_PW(NINT_BF16, false); }
   else { if (db_partial) NINT_PW(NINT_F32, true); else NINT_PW(NINT_F32, false); }
 #undef NINT_PW
   NINT_LAUNCH_CHECK();
   return NINT_OK;
+}
+
+extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
+                                       const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
+                                       float* db_partial, void* stream) {
+  return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, db_partial, false, stream);
 }
 
 // ------------------------------------------------------------------------------ 1x1 head
@@ -636,7 +643,7 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
 // train.py:102,105: crop, MSELoss + L1Loss (mean).  Two launches on the same stream:
 //  (1) per-block partial sums in double (fixed order), (2) one block folds them, writes
 //  the loss and adds to the 5 running statistics.  dpred = (2(p-y) + sign(p-y)) / n on the crop.
-__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+__global__ __launch_bounds__(1024) void loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ y,
                                                            float* __restrict__ dpred, double* __restrict__ partial,
                                                            int N, int O, int H, int W, int oy, int ox, int Hc, int Wc) {
   const size_t total = (size_t)N * O * H * W;
@@ -660,10 +667,10 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
     }
     if (dpred) dpred[i] = g;
   }
-  __shared__ double red[4][256];
+  __shared__ double red[4][1024];
   red[0][threadIdx.x] = s2; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = sy; red[3][threadIdx.x] = syy;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s)
       for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
     __syncthreads();
@@ -705,7 +712,7 @@ extern "C" int nint_loss_mse_l1_crop(const float* pred, const float* y, float* d
   if ((((uintptr_t)loss_out) & 7) != 0) return NINT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)(loss_out + 2);   // loss_out: [0]=loss, [1]=pad, [2..] = 256*4 doubles
-  hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, pred, y, dpred, partial, N, O, H, W, oy, ox, Hc, Wc);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(1024), 0, st, pred, y, dpred, partial, N, O, H, W, oy, ox, Hc, Wc);
   NINT_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, LOSS_BLOCKS, loss_out, stats, (double)N * O * Hc * Wc);
   NINT_LAUNCH_CHECK();

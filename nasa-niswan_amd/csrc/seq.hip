@@ -258,8 +258,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // dh[l] is complete once dgrad(t, l+1) has added its x columns: latest record of ev[l+1]
       if (wave && l + 1 < L) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l + 1], 0));
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
-      rc = nint_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
-                                   s->dh[l], s->dc[l], dG, dbp, S[l]);
+      // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
+      const bool first = t == s->T - 1;
+      rc = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
+                                            s->dh[l], s->dc[l], dG, dbp, first && ((s->zero_dstate >> (2 * l)) & 1), S[l]);
       if (rc != NINT_OK) return rc;
       float* dx_accum = (l > 0) ? s->dh[l - 1]
                                 : (s->need_dx ? s->dx + (size_t)t * B * comp_px * ly->Cxp : nullptr);
@@ -268,7 +270,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // the += into dh[l-1] must follow dgrad(t+1, l-1)'s store: at this point of the enqueue order
       // that is the latest record of ev[l-1] (none yet at t = T-1: the fork covers it)
       if (wave && l > 0 && t < s->T - 1) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));
-      rc = nint_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, S[l]);
+      // the x columns overwrite instead of accumulate where the destination is known to be zero: dx (every time
+      // step has its own slab, written once) and, at the first step, a dh[l-1] flagged zero
+      const bool ow = l == 0 ? true : (first && ((s->zero_dstate >> (2 * (l - 1) + 1)) & 1));
+      rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, ow, S[l]);
       if (rc != NINT_OK) return rc;
       if (wave) NINT_CHECK_HIP(hipEventRecord(pool->ev[l], S[l]));
       if (multi && nch > 1 && t % chunk_steps == 0) {

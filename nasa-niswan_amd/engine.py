@@ -250,12 +250,18 @@ class SeqEngine:
     def backward(self, ws: Workspace, need_dx: bool, zero_state_grads: Sequence[int] = (),
                  dW_out: Optional[Sequence[torch.Tensor]] = None, db_out: Optional[Sequence[torch.Tensor]] = None):
         """BPTT of model.py:253-271.  Precondition: ws.dh[l], ws.dc[l] hold dL/dh_{T-1}, dL/dc_{T-1}
-        (layers listed in ``zero_state_grads`` are zeroed here).  Returns ([dW_l], [db_l], dx or None).
+        (layers listed in ``zero_state_grads`` start from zero state gradients instead).  Returns ([dW_l], [db_l], dx or None).
         ``dW_out`` / ``db_out``: f32 contiguous destinations (e.g. views of a flat gradient bucket)."""
         assert ws.train
+        # layers in ``zero_state_grads`` start BPTT from zero dL/dh, dL/dc: flagged, not filled (the first BPTT step
+        # then neither reads dc nor accumulates into dh).  The top layer's dh always holds the head's gradient.
+        L = len(self.cfgs)
+        mask = 0
         for l in zero_state_grads:
-            ws.dh[l].zero_()
-            ws.dc[l].zero_()
+            mask |= 1 << (2 * l)
+            if l < L - 1:
+                mask |= 1 << (2 * l + 1)
+        ws.seq.zero_dstate = mask
         dWs, dbs = [], []
         s = ws.seq
         for l, cfg in enumerate(self.cfgs):
@@ -270,7 +276,7 @@ class SeqEngine:
             s.db[l] = dbs[-1].data_ptr()
         dx = None
         if need_dx:
-            dx = torch.zeros(ws.T * ws.B * ws.H * ws.W * ws.Cxp0, dtype=torch.float32, device=self.device)
+            dx = torch.empty(ws.T * ws.B * ws.H * ws.W * ws.Cxp0, dtype=torch.float32, device=self.device)
             s.dx = dx.data_ptr()
         s.need_dx = int(need_dx)
         check(self.lib.nint_seq_bwd(C.byref(s), stream_ptr()), "nint_seq_bwd")

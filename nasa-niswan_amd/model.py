@@ -76,11 +76,7 @@ class _ConvLSTMFn(torch.autograd.Function):
         (head_w,) = ctx.saved_tensors
         L = len(eng.cfgs)
         dw_head, db_head = eng.head_backward(ws, head_w, dpred)
-        for l in range(L):
-            ws.dc[l].zero_()
-            if l < L - 1:
-                ws.dh[l].zero_()
-        dWs, dbs, dx = eng.backward(ws, ctx.x_needs_grad)
+        dWs, dbs, dx = eng.backward(ws, ctx.x_needs_grad, zero_state_grads=range(L))
         ctx.rel.release()
         grads = []
         for l in range(L):

@@ -84,11 +84,7 @@ class FusedTrainer:
         eng, ws, pred, dpred = self.forward_loss(X, y, True)
         L = self.model.num_layers
         eng.head_backward(ws, self.model.conv.weight, dpred, dw_out=self._dw_head, db_out=self._db_head)
-        for l in range(L):
-            ws.dc[l].zero_()
-            if l < L - 1:
-                ws.dh[l].zero_()
-        eng.backward(ws, False, dW_out=self._dW, db_out=self._db)
+        eng.backward(ws, False, zero_state_grads=range(L), dW_out=self._dW, db_out=self._db)
         eng.release(ws)
         if self.distributed:
             self.dist.all_reduce(self.flat.grad, op=self.dist.ReduceOp.SUM, group=self.pg)   # RCCL over xGMI
