@@ -19,7 +19,8 @@
  *   halo slab     ET [N][Hh][Wh][Cp]   channels-last, ET = float or bf16, physical zero halo P
  *                                      on every side plus zero slack up to a multiple of 8 rows /
  *                                      32 columns, Cp = channels rounded up to KC (16 f32 / 32 bf16)
- *   compact slab  f32 [N][H][W][Cp]    channels-last, no halo (cell state c, dh, dc)
+ *   compact slab  [N][H][W][Cp]        channels-last, no halo: f32 for the cell state c and dc, ET for the
+ *                                      transient gradients dh, dx (written once, read once per BPTT step)
  *   gate stash    ET [N][H][W][Gc]     Gc = 4*Ch16, column n' = (cblock*4 + gate)*16 + col
  *   image index   n = t*B + b          (time-major so that one launch can span all T)
  */
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 102
+#define NINT_VERSION 103
 #define NINT_DB_ROWS 1024   /* rows of bias-gradient partials one fused pointwise-backward launch writes */
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
@@ -82,9 +83,9 @@ typedef struct nint_seq {
   float* c[NINT_MAX_LAYERS];           /* f32 compact [(T+1)*B][H][W][Chp]: c[0]=initial, c[t+1]=c_t */
   void* gates[NINT_MAX_LAYERS];        /* ET stash [T*B][H][W][4*Ch16] post-activation i,f,g,o (training only; may be NULL) */
   void* dG[NINT_MAX_LAYERS];           /* ET halo slab [T*B][Hh][Wh][4*Ch16] pre-activation gate grads */
-  float* dh[NINT_MAX_LAYERS];          /* f32 compact [B][H][W][Chp] running dL/dh_t (in: dL/dh_{T-1}, out: dL/dh_init) */
+  void* dh[NINT_MAX_LAYERS];           /* ET compact [B][H][W][Chp] running dL/dh_t (in: dL/dh_{T-1}, out: dL/dh_init) */
   float* dc[NINT_MAX_LAYERS];          /* f32 compact [B][H][W][Chp] running dL/dc_t */
-  float* dx;                           /* f32 compact [T*B][H][W][Cxp0] (need_dx only) */
+  void* dx;                            /* ET compact [T*B][H][W][Cxp0] (need_dx only) */
   float* dW[NINT_MAX_LAYERS];          /* f32 OIHW (4Ch, Cx+Ch, k, k) gradient, overwritten */
   float* db[NINT_MAX_LAYERS];          /* f32 (4Ch) gradient, overwritten */
   float* db_partial[NINT_MAX_LAYERS];  /* f32 [T][NINT_DB_ROWS][4*Ch16] bias-gradient partial rows (may be NULL) */
@@ -114,8 +115,8 @@ int nint_pack_btchw(const float* src, void* dst, int B, int T, int C, int Cp, co
 int nint_unpack_halo(const void* src, float* dst, int n0, int N, int C, int Cp, const nint_geom* g,
                      int dtype, void* stream);
 /* (N,C,H,W) f32 <-> compact f32 slab [N][H][W][Cp] */
-int nint_pack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream);
-int nint_unpack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream);
+int nint_pack_compact(const float* src, void* dst, int N, int C, int Cp, int H, int W, int dtype, void* stream);   /* dtype: element type of the compact slab */
+int nint_unpack_compact(const void* src, float* dst, int N, int C, int Cp, int H, int W, int dtype, void* stream);
 
 /* ---- weights ----------------------------------------------------------------------------- */
 /* bytes of the packed fwd / dgrad weight images of one layer */
@@ -137,14 +138,14 @@ int nint_cell_fwd(const nint_layer* ly /*host*/, const nint_geom* g /*host*/, in
  * the stashed gates and c_prev / c_new; writes pre-activation gate grads into the dG halo slab. */
 int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                             const void* gates, const float* c_prev, const float* c_new,
-                            const float* dh, float* dc, void* dG, float* db_partial, void* stream);
+                            const void* dh, float* dc, void* dG, float* db_partial, void* stream);
 /* db_partial (may be NULL): f32 [NINT_DB_ROWS][4*Ch16], one row of bias-gradient partial sums per
  * workgroup of this launch (fused column sum of dG; needs 256 % (Ch16/4) == 0, else NINT_E_SHAPE). */
 
 /* conv backward-data of model.py:220: d cat[x,h] = W^T (*) dG.  h columns are STORED to dh_prev,
  * x columns are ACCUMULATED (+=) into dx_accum (the layer below's dh, or dx); either may be NULL. */
 int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
-                    const void* dG, float* dx_accum, float* dh_prev, void* stream);
+                    const void* dG, void* dx_accum, void* dh_prev, void* stream);
 
 /* conv backward-weight of model.py:220 over N = T*B images in ONE launch (all time steps):
  * dW[o][c][ky][kx] = sum_n,y,x dG[n,y,x,o] * cat[n,y+ky-p,x+kx-p,c] ; db[o] = sum dG.
@@ -176,9 +177,9 @@ int nint_seq_bwd(const nint_seq* s /*host*/, void* stream);
 /* pred (N,O,H,W) f32 = w (O,Ch) . h + b  from halo-slab images [n0, n0+N) */
 int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w, const float* b,
                   float* pred, const nint_geom* g, int dtype, void* stream);
-/* dh (compact f32 [N][H][W][Chp], overwritten) ; dw (O,Ch), db (O) overwritten */
+/* dh (compact ET [N][H][W][Chp], overwritten) ; dw (O,Ch), db (O) overwritten */
 int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
-                  const float* dpred, float* dh, float* dw, float* db, const nint_geom* g, int dtype,
+                  const float* dpred, void* dh, float* dw, float* db, const nint_geom* g, int dtype,
                   float* scratch, size_t scratch_bytes, void* stream);
 /* scratch (may be NULL): >= 256*O*(Ch+1) floats enables the tiled two-stage weight-gradient path. */
 

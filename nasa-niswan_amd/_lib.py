@@ -51,8 +51,8 @@ SIGNATURES = {
     "nint_geom_make": (_I, [_PG, _I, _I, _I]),
     "nint_pack_btchw": (_I, [vp, vp, _I, _I, _I, _I, _PG, _I, vp]),
     "nint_unpack_halo": (_I, [vp, vp, _I, _I, _I, _I, _PG, _I, vp]),
-    "nint_pack_compact": (_I, [vp, vp, _I, _I, _I, _I, _I, vp]),
-    "nint_unpack_compact": (_I, [vp, vp, _I, _I, _I, _I, _I, vp]),
+    "nint_pack_compact": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, vp]),
+    "nint_unpack_compact": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, vp]),
     "nint_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "nint_pack_weights": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, vp]),
     "nint_cell_fwd": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
@@ -92,7 +92,7 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nint_version() != 102:
+    if lib.nint_version() != 103:
         raise NintError("libnint_hip.so version mismatch")
     _lib = lib
     return lib

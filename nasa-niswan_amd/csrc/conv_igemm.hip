@@ -363,11 +363,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
           const int n = (nt0 + j) * 16 + c4;
           if (n < a.C0p) {
             if (a.out0) {
-              f32x4_t* d = (f32x4_t*)(a.out0 + pix * a.C0p + n);
-              *d = a.out0_overwrite ? acc[i][j] : *d + acc[i][j];
+              const size_t o = pix * a.C0p + n;
+              store_vec4<DT>(a.out0, o, a.out0_overwrite ? acc[i][j] : load_vec4<DT>(a.out0, o) + acc[i][j]);
             }
           } else if (a.out1) {
-            *(f32x4_t*)(a.out1 + pix * a.C1p + (n - a.C0p)) = acc[i][j];
+            store_vec4<DT>(a.out1, pix * a.C1p + (n - a.C0p), acc[i][j]);
           }
         }
       }
@@ -466,12 +466,12 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
 }
 
 extern "C" int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
-                               const void* dG, float* dx_accum, float* dh_prev, void* stream) {
+                               const void* dG, void* dx_accum, void* dh_prev, void* stream) {
   return nint_internal_conv_dgrad(ly, g, dtype, N, dG, dx_accum, dh_prev, false, stream);
 }
 
-int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, float* dx_accum,
-                             float* dh_prev, bool overwrite_dx, void* stream) {
+int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
+                             void* dh_prev, bool overwrite_dx, void* stream) {
   if (!ly || !g || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!dx_accum && !dh_prev) return NINT_OK;
@@ -489,7 +489,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.NTt = (ly->Cxp + ly->Chp) / 16;
   a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
   a.H = g->H; a.W = g->W; a.P = g->P; a.Hh = g->Hh; a.Wh = g->Wh;
-  a.out0 = dx_accum; a.out1 = dh_prev;
+  a.out0 = (char*)dx_accum; a.out1 = (char*)dh_prev;
   a.out0_overwrite = overwrite_dx ? 1 : 0;
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
   // only the n-tiles whose destination exists are computed

@@ -69,6 +69,15 @@ template <> __device__ __forceinline__ void store_vec4<NINT_BF16>(void* p, size_
   *(u32x2_t*)((uint16_t*)p + i) = w;
 }
 
+// 4 consecutive elements as f32 (16-byte f32 / 8-byte bf16 vector load); i must be a multiple of 4
+template <int DT> __device__ __forceinline__ f32x4_t load_vec4(const void* p, size_t i);
+template <> __device__ __forceinline__ f32x4_t load_vec4<NINT_F32>(const void* p, size_t i) { return *(const f32x4_t*)((const float*)p + i); }
+template <> __device__ __forceinline__ f32x4_t load_vec4<NINT_BF16>(const void* p, size_t i) {
+  const u32x2_t w = *(const u32x2_t*)((const uint16_t*)p + i);
+  return (f32x4_t){__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                   __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+}
+
 // One K-step of D += A*B on a 16x16 tile from two 16-byte fragments.
 //   bf16: lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], j=0..7
 //   f32 : four MFMAs; in MFMA j lane l supplies A[row l&15][k = l>>4] = element j of its fragment,
@@ -119,15 +128,15 @@ struct ConvArgs {
   char* gates_out;       // stash [N][H][W][4*Ch16] ET or nullptr
   int Chp, Ch16;
   // DGRAD epilogue
-  float* out0;           // += columns [0, C0p)
-  float* out1;           // =  columns [C0p, C0p+C1p)
+  char* out0;            // += columns [0, C0p)  (ET compact)
+  char* out1;            // =  columns [C0p, C0p+C1p)  (ET compact)
   int C0p, C1p;
   int out0_overwrite;    // 1: columns [0, C0p) are stored, not accumulated (the destination is known to be zero)
 };
 
 // internal entry points shared between translation units (not part of the C ABI)
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
-                                     const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
+                                     const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                      float* db_partial, bool dc_zero, void* stream);
-int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, float* dx_accum,
-                             float* dh_prev, bool overwrite_dx, void* stream);
+int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
+                             void* dh_prev, bool overwrite_dx, void* stream);

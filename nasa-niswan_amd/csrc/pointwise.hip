@@ -90,7 +90,8 @@ __global__ void unpack_halo_kernel(const void* __restrict__ src, float* __restri
   }
 }
 
-__global__ void pack_compact_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int Cp,
+template <int DT>
+__global__ void pack_compact_kernel(const float* __restrict__ src, void* __restrict__ dst, int N, int C, int Cp,
                                     int H, int W) {
   const size_t total = (size_t)N * H * W * Cp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -99,11 +100,12 @@ __global__ void pack_compact_kernel(const float* __restrict__ src, float* __rest
     const int x = r % W; r /= W;
     const int y = r % H;
     const int n = r / H;
-    dst[i] = c < C ? src[(((size_t)n * C + c) * H + y) * W + x] : 0.f;
+    store_elem<DT>(dst, i, c < C ? src[(((size_t)n * C + c) * H + y) * W + x] : 0.f);
   }
 }
 
-__global__ void unpack_compact_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int Cp,
+template <int DT>
+__global__ void unpack_compact_kernel(const void* __restrict__ src, float* __restrict__ dst, int N, int C, int Cp,
                                       int H, int W) {
   const size_t total = (size_t)N * C * H * W;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -112,7 +114,7 @@ __global__ void unpack_compact_kernel(const float* __restrict__ src, float* __re
     const int y = r % H; r /= H;
     const int c = r % C;
     const int n = r / C;
-    dst[i] = src[(((size_t)n * H + y) * W + x) * Cp + c];
+    dst[i] = load_elem<DT>(src, (((size_t)n * H + y) * W + x) * Cp + c);
   }
 }
 
@@ -157,16 +159,22 @@ extern "C" int nint_unpack_halo(const void* src, float* dst, int n0, int N, int 
   return NINT_OK;
 }
 
-extern "C" int nint_pack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream) {
-  if (!src || !dst || N <= 0 || C <= 0 || Cp < C) return NINT_E_ARG;
-  hipLaunchKernelGGL(pack_compact_kernel, grid1d((size_t)N * H * W * Cp), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
+extern "C" int nint_pack_compact(const float* src, void* dst, int N, int C, int Cp, int H, int W, int dtype, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || Cp < C || (dtype != NINT_F32 && dtype != NINT_BF16)) return NINT_E_ARG;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(pack_compact_kernel<NINT_BF16>, grid1d((size_t)N * H * W * Cp), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
+  else
+    hipLaunchKernelGGL(pack_compact_kernel<NINT_F32>, grid1d((size_t)N * H * W * Cp), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
 
-extern "C" int nint_unpack_compact(const float* src, float* dst, int N, int C, int Cp, int H, int W, void* stream) {
-  if (!src || !dst || N <= 0 || C <= 0 || Cp < C) return NINT_E_ARG;
-  hipLaunchKernelGGL(unpack_compact_kernel, grid1d((size_t)N * C * H * W), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
+extern "C" int nint_unpack_compact(const void* src, float* dst, int N, int C, int Cp, int H, int W, int dtype, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || Cp < C || (dtype != NINT_F32 && dtype != NINT_BF16)) return NINT_E_ARG;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(unpack_compact_kernel<NINT_BF16>, grid1d((size_t)N * C * H * W), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
+  else
+    hipLaunchKernelGGL(unpack_compact_kernel<NINT_F32>, grid1d((size_t)N * C * H * W), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, Cp, H, W);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
@@ -268,16 +276,9 @@ extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, vo
 // Per (pixel, hidden channel), SURVEY.md section 8 a-5 / autograd of model.py:223-229:
 //   tc = tanh(c'), do = dh*tc, dc += dh*o*(1-tc^2), di = dc*g, df = dc*c, dg = dc*i, dc_prev = dc*f
 //   dGi = di*i*(1-i), dGf = df*f*(1-f), dGg = dg*(1-g^2), dGo = do*o*(1-o)
-// Reads the gate stash (ET), c_prev / c_new / dh / dc (f32); writes dG into its halo slab (ET,
+// Reads the gate stash and dh (ET), c_prev / c_new / dc (f32); writes dG into its halo slab (ET,
 // interior only) and dc_prev in place.  One thread per (pixel, channel), channel fastest.
 // 4 consecutive elements as f32 (16-byte f32 / 8-byte bf16 vector load); i must be a multiple of 4
-template <int DT> __device__ __forceinline__ f32x4_t load_vec4(const void* p, size_t i);
-template <> __device__ __forceinline__ f32x4_t load_vec4<NINT_F32>(const void* p, size_t i) { return *(const f32x4_t*)((const float*)p + i); }
-template <> __device__ __forceinline__ f32x4_t load_vec4<NINT_BF16>(const void* p, size_t i) {
-  const u32x2_t w = *(const u32x2_t*)((const uint16_t*)p + i);
-  return (f32x4_t){bf2f((uint16_t)(w[0] & 0xffff)), bf2f((uint16_t)(w[0] >> 16)), bf2f((uint16_t)(w[1] & 0xffff)), bf2f((uint16_t)(w[1] >> 16))};
-}
-
 // One thread per (pixel, 4 consecutive hidden channels): every access is a 16-byte (f32) or 8-byte
 // (bf16) vector.  With FUSE_DB each thread keeps the SAME channel quad over its grid-stride loop
 // (256 % (Ch16/4) == 0), accumulates the 16 bias-gradient partial sums in registers and the block
@@ -285,7 +286,7 @@ template <> __device__ __forceinline__ f32x4_t load_vec4<NINT_BF16>(const void* 
 // by nint_conv_wgrad.  This replaces a separate full pass over dG.
 template <int DT, bool FUSE_DB>
 __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
-                                          const float* __restrict__ c_new, const float* __restrict__ dh,
+                                          const float* __restrict__ c_new, const void* __restrict__ dh,
                                           float* __restrict__ dc, void* __restrict__ dG, float* __restrict__ db_partial,
                                           int N, int H, int W, int P, int Hh, int Wh, int Ch16, int Chp, int dc_zero) {
   const int nq = Ch16 >> 2;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __r
     f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
     if (c_prev) cp = *(const f32x4_t*)(c_prev + ci);
     const f32x4_t cn = *(const f32x4_t*)(c_new + ci);
-    const f32x4_t dhv = *(const f32x4_t*)(dh + ci);
+    const f32x4_t dhv = load_vec4<DT>(dh, ci);
     f32x4_t dcv = {0.f, 0.f, 0.f, 0.f};
     if (!dc_zero) dcv = *(const f32x4_t*)(dc + ci);
     f32x4_t o_i, o_f, o_g, o_o, dcp;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __r
 }
 
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
-                                     const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
+                                     const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                      float* db_partial, bool dc_zero, void* stream) {
   if (!ly || !g || !gates || !c_new || !dh || !dc || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
@@ -373,7 +374,7 @@ int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, i
 }
 
 extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
-                                       const float* c_prev, const float* c_new, const float* dh, float* dc, void* dG,
+                                       const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                        float* db_partial, void* stream) {
   return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, db_partial, false, stream);
 }
@@ -431,9 +432,9 @@ __global__ void head_fwd_wide_kernel(const void* __restrict__ h, int n0, int N, 
 
 // dh[n][y][x][c] = sum_o w[o][c] * dpred[n][o][y][x].  One thread per pixel (dpred planes read coalesced
 // along x, weights wave-uniform), the padded channel vector is written with 16-byte stores.
-template <int CHV>
+template <int DT, int CHV>
 __global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restrict__ w, const float* __restrict__ dpred,
-                                                          float* __restrict__ dh, int N, int Ch, int Chp, int O, int H, int W) {
+                                                          void* __restrict__ dh, int N, int Ch, int Chp, int O, int H, int W) {
   const size_t npix = (size_t)N * H * W;
   const size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (pix >= npix) return;
@@ -451,10 +452,11 @@ __global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restric
   }
 #pragma unroll
   for (int c = 0; c < CHV; c += 4)
-    if (c < Chp) *(f32x4_t*)(dh + pix * Chp + c) = (f32x4_t){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+    if (c < Chp) store_vec4<DT>(dh, pix * Chp + c, (f32x4_t){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
 }
 
-__global__ void head_bwd_dh_wide_kernel(const float* __restrict__ w, const float* __restrict__ dpred, float* __restrict__ dh,
+template <int DT>
+__global__ void head_bwd_dh_wide_kernel(const float* __restrict__ w, const float* __restrict__ dpred, void* __restrict__ dh,
                                         int N, int Ch, int Chp, int O, int H, int W) {
   const size_t total = (size_t)N * H * W * Chp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -465,7 +467,7 @@ __global__ void head_bwd_dh_wide_kernel(const float* __restrict__ w, const float
     float acc = 0.f;
     if (c < Ch)
       for (int o = 0; o < O; ++o) acc += w[o * Ch + c] * dpred[((size_t)n * O + o) * H * W + yx];
-    dh[i] = acc;
+    store_elem<DT>(dh, i, acc);
   }
 }
 
@@ -601,7 +603,7 @@ extern "C" int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp,
 }
 
 extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w,
-                             const float* dpred, float* dh, float* dw, float* db, const nint_geom* g, int dtype,
+                             const float* dpred, void* dh, float* dw, float* db, const nint_geom* g, int dtype,
                              float* scratch, size_t scratch_bytes, void* stream) {
   if (!h_slab || !w || !dpred || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
@@ -609,12 +611,17 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   if (dh) {
     const size_t npix = (size_t)N * g->H * g->W;
     const dim3 gp((unsigned)((npix + 255) / 256));
-    if (Chp <= 32 && Chp % 4 == 0)
-      hipLaunchKernelGGL(head_bwd_dh_kernel<32>, gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
-    else if (Chp <= 64 && Chp % 4 == 0)
-      hipLaunchKernelGGL(head_bwd_dh_kernel<64>, gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
-    else
-      hipLaunchKernelGGL(head_bwd_dh_wide_kernel, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    const bool b16 = dtype == NINT_BF16;
+    if (Chp <= 32 && Chp % 4 == 0) {
+      if (b16) hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_BF16, 32>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+      else hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_F32, 32>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    } else if (Chp <= 64 && Chp % 4 == 0) {
+      if (b16) hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_BF16, 64>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+      else hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_F32, 64>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    } else {
+      if (b16) hipLaunchKernelGGL(head_bwd_dh_wide_kernel<NINT_BF16>, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+      else hipLaunchKernelGGL(head_bwd_dh_wide_kernel<NINT_F32>, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    }
     NINT_LAUNCH_CHECK();
   }
   const int nout = O * (Ch + 1);

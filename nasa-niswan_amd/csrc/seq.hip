@@ -263,10 +263,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       rc = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
                                             s->dh[l], s->dc[l], dG, dbp, first && ((s->zero_dstate >> (2 * l)) & 1), S[l]);
       if (rc != NINT_OK) return rc;
-      float* dx_accum = (l > 0) ? s->dh[l - 1]
-                                : (s->need_dx ? s->dx + (size_t)t * B * comp_px * ly->Cxp : nullptr);
+      void* dx_accum = (l > 0) ? s->dh[l - 1]
+                               : (s->need_dx ? (void*)((char*)s->dx + (size_t)t * B * comp_px * ly->Cxp * es) : nullptr);
       // at t == 0 with a zero initial state nobody consumes d/dh_{-1}
-      float* dh_prev = (t == 0 && !s->has_init_state) ? nullptr : s->dh[l];
+      void* dh_prev = (t == 0 && !s->has_init_state) ? nullptr : s->dh[l];
       // the += into dh[l-1] must follow dgrad(t+1, l-1)'s store: at this point of the enqueue order
       // that is the latest record of ev[l-1] (none yet at t = T-1: the fork covers it)
       if (wave && l > 0 && t < s->T - 1) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));

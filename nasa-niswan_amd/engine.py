@@ -63,7 +63,7 @@ class Workspace:
             if train:
                 self.gates.append(torch.empty(T * B * comp_px * 4 * Ch16 * es, **u8))
                 self.dG.append(torch.zeros(T * B * halo_px * 4 * Ch16 * es, **u8))
-                self.dh.append(torch.zeros(B * comp_px * Chp, **f32))
+                self.dh.append(torch.zeros(B * comp_px * Chp * es, **u8))      # ET: transient gradient, read once per step
                 self.dc.append(torch.zeros(B * comp_px * Chp, **f32))
                 self.dbp.append(torch.zeros(T * _lib.NINT_DB_ROWS * 4 * Ch16, **f32))
         self.dx = None
@@ -197,7 +197,7 @@ class SeqEngine:
                 check(self.lib.nint_pack_btchw(ptr(hh), C.c_void_p(ws.h_view(self, l, 0)), B, 1, cfg.Ch, Chp, g, self.dt, st),
                       "pack h0")
                 cc = c0[l].detach().float().contiguous()
-                check(self.lib.nint_pack_compact(ptr(cc), C.c_void_p(ws.c_view(self, l, 0)), B, cfg.Ch, Chp, H, W, st),
+                check(self.lib.nint_pack_compact(ptr(cc), C.c_void_p(ws.c_view(self, l, 0)), B, cfg.Ch, Chp, H, W, NINT_F32, st),
                       "pack c0")
         check(self.lib.nint_seq_fwd(C.byref(ws.seq), st), "nint_seq_fwd")
 
@@ -215,7 +215,7 @@ class SeqEngine:
         Chp = cfg.padded(self.kc)[2]
         out = torch.empty(ws.B, cfg.Ch, ws.H, ws.W, dtype=torch.float32, device=self.device)
         check(self.lib.nint_unpack_compact(C.c_void_p(ws.c_view(self, l, ws.T)), ptr(out), ws.B, cfg.Ch, Chp, ws.H, ws.W,
-                                           stream_ptr()), "nint_unpack_compact")
+                                           NINT_F32, stream_ptr()), "nint_unpack_compact")
         return out
 
     def head_forward(self, ws: Workspace, w: torch.Tensor, b: Optional[torch.Tensor], slot: Optional[int] = None):
@@ -276,7 +276,7 @@ class SeqEngine:
             s.db[l] = dbs[-1].data_ptr()
         dx = None
         if need_dx:
-            dx = torch.empty(ws.T * ws.B * ws.H * ws.W * ws.Cxp0, dtype=torch.float32, device=self.device)
+            dx = torch.empty(ws.T * ws.B * ws.H * ws.W * ws.Cxp0 * self.es, dtype=torch.uint8, device=self.device)   # ET compact
             s.dx = dx.data_ptr()
         s.need_dx = int(need_dx)
         check(self.lib.nint_seq_bwd(C.byref(s), stream_ptr()), "nint_seq_bwd")
@@ -286,7 +286,7 @@ class SeqEngine:
             # compact [T*B][H][W][Cxp0] -> (B,T,C,H,W)
             C0 = self.cfgs[0].Cx
             tb = torch.empty(ws.T * ws.B, C0, ws.H, ws.W, dtype=torch.float32, device=self.device)
-            check(self.lib.nint_unpack_compact(ptr(dx), ptr(tb), ws.T * ws.B, C0, ws.Cxp0, ws.H, ws.W, stream_ptr()),
+            check(self.lib.nint_unpack_compact(ptr(dx), ptr(tb), ws.T * ws.B, C0, ws.Cxp0, ws.H, ws.W, self.dt, stream_ptr()),
                   "unpack dx")
             dx_out = tb.view(ws.T, ws.B, C0, ws.H, ws.W).transpose(0, 1).contiguous()
         return dWs, dbs, dx_out
@@ -298,17 +298,17 @@ class SeqEngine:
         dh = torch.empty(ws.B, cfg.Ch, ws.H, ws.W, dtype=torch.float32, device=self.device)
         dc = torch.empty_like(dh)
         st = stream_ptr()
-        check(self.lib.nint_unpack_compact(ptr(ws.dh[l]), ptr(dh), ws.B, cfg.Ch, Chp, ws.H, ws.W, st), "unpack dh")
-        check(self.lib.nint_unpack_compact(ptr(ws.dc[l]), ptr(dc), ws.B, cfg.Ch, Chp, ws.H, ws.W, st), "unpack dc")
+        check(self.lib.nint_unpack_compact(ptr(ws.dh[l]), ptr(dh), ws.B, cfg.Ch, Chp, ws.H, ws.W, self.dt, st), "unpack dh")
+        check(self.lib.nint_unpack_compact(ptr(ws.dc[l]), ptr(dc), ws.B, cfg.Ch, Chp, ws.H, ws.W, NINT_F32, st), "unpack dc")
         return dh, dc
 
     def set_state_grads(self, ws: Workspace, l: int, dh: Optional[torch.Tensor], dc: Optional[torch.Tensor]):
         cfg = self.cfgs[l]
         Chp = cfg.padded(self.kc)[2]
         st = stream_ptr()
-        for src, dst in ((dh, ws.dh[l]), (dc, ws.dc[l])):
+        for src, dst, dt in ((dh, ws.dh[l], self.dt), (dc, ws.dc[l], NINT_F32)):
             if src is None:
                 dst.zero_()
             else:
                 s2 = src.detach().float().contiguous()
-                check(self.lib.nint_pack_compact(ptr(s2), ptr(dst), ws.B, cfg.Ch, Chp, ws.H, ws.W, st), "pack dstate")
+                check(self.lib.nint_pack_compact(ptr(s2), ptr(dst), ws.B, cfg.Ch, Chp, ws.H, ws.W, dt, st), "pack dstate")

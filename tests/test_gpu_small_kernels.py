@@ -55,9 +55,9 @@ def test_pack_unpack_roundtrip_and_zero_halo(lib, dt):
     # compact slabs
     c = torch.randn(3, Cc, H, W, device="cuda")
     cs = torch.empty(3 * H * W * Cp, device="cuda")
-    assert lib.nint_pack_compact(P(c), P(cs), 3, Cc, Cp, H, W, None) == 0
+    assert lib.nint_pack_compact(P(c), P(cs), 3, Cc, Cp, H, W, 0, None) == 0
     c2 = torch.empty_like(c)
-    assert lib.nint_unpack_compact(P(cs), P(c2), 3, Cc, Cp, H, W, None) == 0
+    assert lib.nint_unpack_compact(P(cs), P(c2), 3, Cc, Cp, H, W, 0, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(c, c2)
 

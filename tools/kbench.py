@@ -50,7 +50,7 @@ def main():
     X = torch.randn(B, T, args.C, H, W, device="cuda")
     eng.forward(ws, X)       # fills every slab with realistic (random-data) values
     for l in range(3):
-        ws.dh[l].normal_(); ws.dc[l].normal_()
+        ws.dh[l].view(torch.bfloat16 if eng.es == 2 else torch.float32).normal_(); ws.dc[l].normal_()
     g, st = C.byref(ws.g), None
     es = eng.es
     halo_px, comp_px = ws.g.Hh * ws.g.Wh, H * W
@@ -92,7 +92,7 @@ def main():
                                                C.c_void_p(ws.c[l].data_ptr() + cs), C.c_void_p(ws.c[l].data_ptr() + 2 * cs),
                                                C.c_void_p(ws.dh[l].data_ptr()), C.c_void_p(ws.dc[l].data_ptr()),
                                                C.c_void_p(ws.dG[l].data_ptr() + dgs), C.c_void_p(ws.dbp[l].data_ptr()), st) == 0
-        run(f"pointwise{l}", pw, None, B * comp_px * ly.Ch16 * (8 * es + 24))
+        run(f"pointwise{l}", pw, None, B * comp_px * ly.Ch16 * (9 * es + 16))   # gates+dG (ET), dh (ET), c_prev, c_new, dc r+w (f32)
     # fill dG for every t so that wgrad sees random data
     for l in range(3):
         ws.dG[l].view(torch.bfloat16 if es == 2 else torch.float32).normal_(std=0.05)
