@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
     const char* Bs = Bwave + (size_t)(c_begin * taps + s_lo) * bstep;
     // B ring: BD K-steps of weight fragments in flight per wave (L2 latency under load is several
     // K-steps long and only two waves share a SIMD, so one step of prefetch is not enough)
-    // The ring loop is kept BRANCH-FREE (reloads are unconditional, their address is clamped to the
-    // slice's last step) so that the compiler can count outstanding loads and emits
+    // The ring loop is kept BRANCH-FREE (reloads are unconditional; past the slice's last step the pointer
+    // stops advancing and the last step is re-read) so that the compiler can count outstanding loads and emits
     // s_waitcnt vmcnt((BD-1)*NTW) instead of draining the ring with vmcnt(0) at every step.
     u32x4_t bq[BD][NTW];
     int b_rem = s_hi - 1 - s_lo;                                    // steps the load pointer may still advance
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       constexpr int NG = MT / AG;              // row groups per K-step
       constexpr int NBUF = NINT_ABUF;          // register groups; the reads run NBUF-1 groups ahead of the MFMAs
       constexpr int LA = NBUF - 1;
-      static_assert(MT % AG == 0 && LA >= 1 && LA <= NG && (NG * BD) % NBUF == 0 && NG % NBUF % 1 == 0, "group rotation must close over the unrolled ring");
+      static_assert(MT % AG == 0 && LA >= 1 && LA <= NG && (NG * BD) % NBUF == 0, "group rotation must close over the unrolled ring");
       u32x4_t ax[NBUF * AG];
       int va = (int)(cl * chunk_bytes + (tyy * HWt + txx) * 16) + a_lane_off;   // LDS byte offset of this step's fragment (row 0)
       const int d_row = (HWt - (k - 1)) * 16;                                  // tap (ty, k-1) -> (ty+1, 0)
