@@ -119,32 +119,26 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   for (int c_begin = 0; c_begin < nchunks; c_begin += a.cpf) {
     const int c_cnt = min(a.cpf, nchunks - c_begin);
     if (c_begin > 0) __syncthreads();          // every wave is done reading the previous image
-    // ---- stage the halo tile for chunks [c_begin, c_begin+c_cnt): global -> regs -> LDS ----
+    // ---- stage the halo tile for chunks [c_begin, c_begin+c_cnt): global -> LDS ----
     const int a_units = c_cnt * 4 * NHPp;
-    constexpr int FB = 8;                      // loads in flight per thread
-    for (int u0 = tid; u0 < a_units; u0 += NTH * FB) {
-      u32x4_t fr[FB];
-#pragma unroll
-      for (int f = 0; f < FB; ++f) {
-        const int u = u0 + f * NTH;
-        const int hp = u % NHPp;
-        const int cq = u / NHPp;               // cl*4 + q
-        if (u < a_units && hp < NHP) {
-          const int q = cq & 3, cl = cq >> 2;
-          const int hy = hp / HWt;
-          const int hx = hp - hy * HWt;
-          const int c = c_begin + cl;
-          const char* src = (c < a.nchunk0)
-              ? base0 + ((long)hy * a.Wh + hx) * a.pix_stride0 + c * 64 + q * 16
-              : base1 + ((long)hy * a.Wh + hx) * a.pix_stride1 + (c - a.nchunk0) * 64 + q * 16;
-          fr[f] = *(const u32x4_t*)src;
-        }
-      }
-#pragma unroll
-      for (int f = 0; f < FB; ++f) {
-        const int u = u0 + f * NTH;
-        if (u < a_units && (u % NHPp) < NHP) *(u32x4_t*)(smem + (size_t)u * 16) = fr[f];
-      }
+    // LDS-DMA fill: one global_load_lds_dwordx4 per wave moves 64 consecutive 16-byte units of the image
+    // (wave-uniform LDS base + lane*16; the SOURCE address is per lane), no VGPR round trip, so the whole
+    // image is in flight at once instead of FB loads per thread.  Units of the pad pixels re-read pixel 0
+    // (their LDS slots are never used); a_units is a multiple of 64.  The barrier below drains the DMA.
+    for (int ub = wave * 64; ub < a_units; ub += 4 * 64) {
+      const int u = ub + lane;
+      int hp = u % NHPp;
+      const int cq = u / NHPp;                 // cl*4 + q
+      hp = hp < NHP ? hp : 0;
+      const int q = cq & 3, cl = cq >> 2;
+      const int hy = hp / HWt;
+      const int hx = hp - hy * HWt;
+      const int c = c_begin + cl;
+      const char* src = (c < a.nchunk0)
+          ? base0 + ((long)hy * a.Wh + hx) * a.pix_stride0 + c * 64 + q * 16
+          : base1 + ((long)hy * a.Wh + hx) * a.pix_stride1 + (c - a.nchunk0) * 64 + q * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + (size_t)ub * 16), 16, 0, 0);
     }
     // ---- this wave's K-slice of the fill: steps [s_lo, s_hi) of c_cnt*taps ----
     const int nsteps = c_cnt * taps;
