@@ -319,24 +319,44 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
         const int y = y0 + (i + wk * Q) % MT;
-        if (y < a.H && x < a.W) {
-          const size_t pix = ((size_t)img * a.H + y) * a.W + x;
-          f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
-          if (a.c_prev) cp = *(const f32x4_t*)(a.c_prev + pix * a.Chp + ch);
-          f32x4_t gi, gf, gg, go, cn, hn;
+        const bool ok = y < a.H && x < a.W;      // (the lane exchange below needs every lane: no divergent block)
+        const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+        f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
+        if (ok && a.c_prev) cp = *(const f32x4_t*)(a.c_prev + pix * a.Chp + ch);
+        f32x4_t gi, gf, gg, go, cn, hn;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            gi[r] = sigmoidf_(acc[i][cb * 4 + 0][r] + bi[r]);
-            gf[r] = sigmoidf_(acc[i][cb * 4 + 1][r] + bf_[r]);
-            gg[r] = tanhf_(acc[i][cb * 4 + 2][r] + bg[r]);
-            go[r] = sigmoidf_(acc[i][cb * 4 + 3][r] + bo[r]);
-            cn[r] = cp[r] * gf[r] + gi[r] * gg[r];       // model.py:228
-            hn[r] = go[r] * tanhf_(cn[r]);               // model.py:229
-          }
+        for (int r = 0; r < 4; ++r) {
+          gi[r] = sigmoidf_(acc[i][cb * 4 + 0][r] + bi[r]);
+          gf[r] = sigmoidf_(acc[i][cb * 4 + 1][r] + bf_[r]);
+          gg[r] = tanhf_(acc[i][cb * 4 + 2][r] + bg[r]);
+          go[r] = sigmoidf_(acc[i][cb * 4 + 3][r] + bo[r]);
+          cn[r] = cp[r] * gf[r] + gi[r] * gg[r];       // model.py:228
+          hn[r] = go[r] * tanhf_(cn[r]);               // model.py:229
+        }
+        if (ok) {
           *(f32x4_t*)(a.c_out + pix * a.Chp + ch) = cn;
           const size_t hpix = ((size_t)img * a.Hh + (y + a.P)) * a.Wh + (x + a.P);
           store_vec4<DT>(a.h_out, hpix * a.Chp + ch, hn);
-          if (a.gates_out) {
+        }
+        if (a.gates_out) {
+          if constexpr (DT == NINT_BF16) {
+            // The epilogue is store-ISSUE-bound (8-byte stores): lane rows 2r and 2r+1 (channel quads 8r..8r+3 and
+            // 8r+4..8r+7 of the same pixel) trade halves with v_permlane16_swap so that the even row stores gates
+            // i and f, the odd row g and o, each as ONE 16-byte vector of 8 channels: 2 stores instead of 4.
+            auto pk = [](float lo, float hi) __attribute__((always_inline)) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); };
+            typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+            const u2_t ig0 = __builtin_amdgcn_permlane16_swap(pk(gi[0], gi[1]), pk(gg[0], gg[1]), false, false);
+            const u2_t ig1 = __builtin_amdgcn_permlane16_swap(pk(gi[2], gi[3]), pk(gg[2], gg[3]), false, false);
+            const u2_t fo0 = __builtin_amdgcn_permlane16_swap(pk(gf[0], gf[1]), pk(go[0], go[1]), false, false);
+            const u2_t fo1 = __builtin_amdgcn_permlane16_swap(pk(gf[2], gf[3]), pk(go[2], go[3]), false, false);
+            // even row: (own, partner) of the first operand = gate i / f; odd row: (partner, own) of the second = g / o
+            const int odd = (lane >> 4) & 1, chb = (lane >> 5) * 8;
+            const size_t gb = pix * (size_t)(4 * a.Ch16) + (size_t)cblock * 64 + chb;
+            if (ok) {
+              *(u32x4_t*)((uint16_t*)a.gates_out + gb + (odd ? 32 : 0)) = (u32x4_t){ig0[0], ig1[0], ig0[1], ig1[1]};
+              *(u32x4_t*)((uint16_t*)a.gates_out + gb + (odd ? 48 : 16)) = (u32x4_t){fo0[0], fo1[0], fo0[1], fo1[1]};
+            }
+          } else if (ok) {
             const size_t gb = pix * (size_t)(4 * a.Ch16) + (size_t)cblock * 64 + c4;
             store_vec4<DT>(a.gates_out, gb + 0, gi);
             store_vec4<DT>(a.gates_out, gb + 16, gf);
