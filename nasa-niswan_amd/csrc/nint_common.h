@@ -95,12 +95,15 @@ template <> __device__ __forceinline__ f32x4_t mma_step<NINT_F32>(u32x4_t a, u32
   return c;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// tanh through exp; exact to ~1e-7 relative for the |x| range of LSTM pre-activations and
-// saturates cleanly for large |x| (exp overflow -> inf -> 1 - 0).
+// Reciprocal by v_rcp_f32 (1 ulp): an IEEE division costs ~10 VALU instructions (div_scale x2, rcp, 4 fma,
+// div_fmas, div_fixup) and the LSTM epilogue does five per element -- it was half of the epilogue's VALU work.
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+// tanh through exp; exact to ~2e-7 relative for the |x| range of LSTM pre-activations and
+// saturates cleanly for large |x| (exp underflow -> 0 -> (1 - 0) * rcp(1 + 0) = 1).
 __device__ __forceinline__ float tanhf_(float x) {
   float e = __expf(-2.0f * fabsf(x));
-  float t = (1.0f - e) / (1.0f + e);
+  float t = (1.0f - e) * rcpf_(1.0f + e);
   return copysignf(t, x);
 }
 
