@@ -312,11 +312,12 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
       const int y = y0 + (i + wk * Q) % MT, xq = x0 + (lane & 15);
+      const float* crow = a.c_prev + ((size_t)img * a.H + y) * a.W * a.Chp;     // wave-uniform row base
 #pragma unroll
       for (int cb = 0; cb < NTW / 4; ++cb) {
         cpv[i][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (a.c_prev && y < a.H && xq < a.W)
-          cpv[i][cb] = *(const f32x4_t*)(a.c_prev + (((size_t)img * a.H + y) * a.W + xq) * a.Chp + (nt0 / 4 + cb) * 16 + 4 * (lane >> 4));
+          cpv[i][cb] = *(const f32x4_t*)(crow + (unsigned)(xq * a.Chp + (nt0 / 4 + cb) * 16 + 4 * (lane >> 4)));
       }
     }
   }
@@ -332,11 +333,17 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       const f32x4_t bf_ = *(const f32x4_t*)(a.bias + (cblock * 4 + 1) * 16 + c4);
       const f32x4_t bg = *(const f32x4_t*)(a.bias + (cblock * 4 + 2) * 16 + c4);
       const f32x4_t bo = *(const f32x4_t*)(a.bias + (cblock * 4 + 3) * 16 + c4);
+      // addresses = wave-uniform row base (scalar arithmetic) + a 32-bit lane offset that is the same for every row
+      const int Gc = 4 * a.Ch16;
+      const int odd = (lane >> 4) & 1, chb = (lane >> 5) * 8;   // (bf16 gate stash: see below)
+      const unsigned lo_c = (unsigned)(x * a.Chp + ch);
+      const unsigned lo_h = (unsigned)((x + a.P) * a.Chp + ch);
+      const unsigned lo_g = (unsigned)(x * Gc + cblock * 64) + (DT == NINT_BF16 ? (unsigned)(chb + (odd ? 32 : 0)) : (unsigned)c4);
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
         const int y = y0 + (i + wk * Q) % MT;
         const bool ok = y < a.H && x < a.W;      // (the lane exchange below needs every lane: no divergent block)
-        const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+        const size_t rowpix = ((size_t)img * a.H + y) * a.W;
         const f32x4_t cp = cpv[i][cb];
         f32x4_t gi, gf, gg, go, cn, hn;
 #pragma unroll
@@ -349,34 +356,33 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
           hn[r] = go[r] * tanhf_(cn[r]);               // model.py:229
         }
         if (ok) {
-          *(f32x4_t*)(a.c_out + pix * a.Chp + ch) = cn;
-          const size_t hpix = ((size_t)img * a.Hh + (y + a.P)) * a.Wh + (x + a.P);
-          store_vec4<DT>(a.h_out, hpix * a.Chp + ch, hn);
+          *(f32x4_t*)(a.c_out + rowpix * a.Chp + lo_c) = cn;
+          char* hrow = a.h_out + (((size_t)img * a.Hh + (y + a.P)) * a.Wh) * a.Chp * Elem<DT>::ES;
+          store_vec4<DT>(hrow, lo_h, hn);
         }
         if (a.gates_out) {
           if constexpr (DT == NINT_BF16) {
             // The epilogue is store-ISSUE-bound (8-byte stores): lane rows 2r and 2r+1 (channel quads 8r..8r+3 and
             // 8r+4..8r+7 of the same pixel) trade halves with v_permlane16_swap so that the even row stores gates
             // i and f, the odd row g and o, each as ONE 16-byte vector of 8 channels: 2 stores instead of 4.
-            auto pk = [](float lo, float hi) __attribute__((always_inline)) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); };
+            auto pk = [](float lo, float hi) __attribute__((always_inline)) { return pack_bf16x2(lo, hi); };
             typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
             const u2_t ig0 = __builtin_amdgcn_permlane16_swap(pk(gi[0], gi[1]), pk(gg[0], gg[1]), false, false);
             const u2_t ig1 = __builtin_amdgcn_permlane16_swap(pk(gi[2], gi[3]), pk(gg[2], gg[3]), false, false);
             const u2_t fo0 = __builtin_amdgcn_permlane16_swap(pk(gf[0], gf[1]), pk(go[0], go[1]), false, false);
             const u2_t fo1 = __builtin_amdgcn_permlane16_swap(pk(gf[2], gf[3]), pk(go[2], go[3]), false, false);
             // even row: (own, partner) of the first operand = gate i / f; odd row: (partner, own) of the second = g / o
-            const int odd = (lane >> 4) & 1, chb = (lane >> 5) * 8;
-            const size_t gb = pix * (size_t)(4 * a.Ch16) + (size_t)cblock * 64 + chb;
             if (ok) {
-              *(u32x4_t*)((uint16_t*)a.gates_out + gb + (odd ? 32 : 0)) = (u32x4_t){ig0[0], ig1[0], ig0[1], ig1[1]};
-              *(u32x4_t*)((uint16_t*)a.gates_out + gb + (odd ? 48 : 16)) = (u32x4_t){fo0[0], fo1[0], fo0[1], fo1[1]};
+              uint16_t* grow = (uint16_t*)a.gates_out + rowpix * Gc;
+              *(u32x4_t*)(grow + lo_g) = (u32x4_t){ig0[0], ig1[0], ig0[1], ig1[1]};        // gate i (even row) / g (odd row)
+              *(u32x4_t*)(grow + lo_g + 16) = (u32x4_t){fo0[0], fo1[0], fo0[1], fo1[1]};   // gate f / o
             }
           } else if (ok) {
-            const size_t gb = pix * (size_t)(4 * a.Ch16) + (size_t)cblock * 64 + c4;
-            store_vec4<DT>(a.gates_out, gb + 0, gi);
-            store_vec4<DT>(a.gates_out, gb + 16, gf);
-            store_vec4<DT>(a.gates_out, gb + 32, gg);
-            store_vec4<DT>(a.gates_out, gb + 48, go);
+            char* grow = a.gates_out + rowpix * Gc * Elem<DT>::ES;
+            store_vec4<DT>(grow, lo_g + 0, gi);
+            store_vec4<DT>(grow, lo_g + 16, gf);
+            store_vec4<DT>(grow, lo_g + 32, gg);
+            store_vec4<DT>(grow, lo_g + 48, go);
           }
         }
       }

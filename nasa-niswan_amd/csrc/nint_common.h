@@ -48,6 +48,12 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(uint16_t, h);
 }
+// two floats -> one dword of two bf16 (low half = first): a single v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
 __device__ __forceinline__ float bf2f(uint16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
 
 template <int DT> __device__ __forceinline__ float load_elem(const void* p, size_t i);
@@ -64,8 +70,8 @@ template <> __device__ __forceinline__ void store_vec4<NINT_F32>(void* p, size_t
 }
 template <> __device__ __forceinline__ void store_vec4<NINT_BF16>(void* p, size_t i, f32x4_t v) {
   u32x2_t w;
-  w[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  w[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  w[0] = pack_bf16x2(v[0], v[1]);
+  w[1] = pack_bf16x2(v[2], v[3]);
   *(u32x2_t*)((uint16_t*)p + i) = w;
 }
 
