@@ -94,11 +94,18 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   const int plane = NHPp * 16;                 // bytes of one g-plane
   const int chunk_bytes = 4 * plane;
 
+  // accumulators start at the gate bias (LSTM epilogue; the tile is D[channel][pixel], so register r of n-tile j
+  // is channel 4*(lane>>4)+r of column block nt0+j) -- only in K-slice 0, whose partial every row sums once
   f32x4_t acc[MT][NTW];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < NTW; ++j) {
+    f32x4_t b0 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_LSTM) {
+      if (wk == 0) b0 = *(const f32x4_t*)(a.bias + (nt0 + j) * 16 + 4 * (lane >> 4));
+    }
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) acc[i][j] = b0;
+  }
 
   const int nchunks = a.nchunk0 + a.nchunk1;
   const char* base0 = a.src0 + (long)img * a.img_stride0 +
@@ -127,11 +134,13 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
     // (their LDS slots are never used); a_units is a multiple of 64.  The barrier below drains the DMA.
     for (int ub = wave * 64; ub < a_units; ub += 4 * 64) {
       const int u = ub + lane;
-      int hp = u % NHPp;
-      const int cq = u / NHPp;                 // cl*4 + q
+      // u / NHPp and hp / HWt by multiply-high with host-side magic numbers (exact for u < 65536, divisor <= 4096):
+      // an integer division by a run-time value costs ~25 VALU instructions, and there are two per unit
+      const int cq = (int)__umulhi((unsigned)u, a.magic_nhpp);   // cl*4 + q
+      int hp = u - cq * NHPp;
       hp = hp < NHP ? hp : 0;
       const int q = cq & 3, cl = cq >> 2;
-      const int hy = hp / HWt;
+      const int hy = (int)__umulhi((unsigned)hp, a.magic_hwt);
       const int hx = hp - hy * HWt;
       const int c = c_begin + cl;
       const char* src = (c < a.nchunk0)
@@ -329,10 +338,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
     for (int cb = 0; cb < NTW / 4; ++cb) {
       const int cblock = nt0 / 4 + cb;
       const int ch = cblock * 16 + c4;
-      const f32x4_t bi = *(const f32x4_t*)(a.bias + (cblock * 4 + 0) * 16 + c4);
-      const f32x4_t bf_ = *(const f32x4_t*)(a.bias + (cblock * 4 + 1) * 16 + c4);
-      const f32x4_t bg = *(const f32x4_t*)(a.bias + (cblock * 4 + 2) * 16 + c4);
-      const f32x4_t bo = *(const f32x4_t*)(a.bias + (cblock * 4 + 3) * 16 + c4);
       // addresses = wave-uniform row base (scalar arithmetic) + a 32-bit lane offset that is the same for every row
       const int Gc = 4 * a.Ch16;
       const int odd = (lane >> 4) & 1, chb = (lane >> 5) * 8;   // (bf16 gate stash: see below)
@@ -348,10 +353,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
         f32x4_t gi, gf, gg, go, cn, hn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          gi[r] = sigmoidf_(acc[i][cb * 4 + 0][r] + bi[r]);
-          gf[r] = sigmoidf_(acc[i][cb * 4 + 1][r] + bf_[r]);
-          gg[r] = tanhf_(acc[i][cb * 4 + 2][r] + bg[r]);
-          go[r] = sigmoidf_(acc[i][cb * 4 + 3][r] + bo[r]);
+          gi[r] = sigmoidf_(acc[i][cb * 4 + 0][r]);      // (bias already in the accumulator)
+          gf[r] = sigmoidf_(acc[i][cb * 4 + 1][r]);
+          gg[r] = tanhf_(acc[i][cb * 4 + 2][r]);
+          go[r] = sigmoidf_(acc[i][cb * 4 + 3][r]);
           cn[r] = cp[r] * gf[r] + gi[r] * gg[r];       // model.py:228
           hn[r] = go[r] * tanhf_(cn[r]);               // model.py:229
         }
@@ -416,6 +421,8 @@ template <int DT, int EPI, int WN, int WK, int NTW, int MT>
 static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   const int NHP = (MT + 2 * a.p) * (16 + 2 * a.p);
   a.nhp_pad = nint_round_up(NHP, 16);
+  a.magic_nhpp = (unsigned)(((1ull << 32) + a.nhp_pad - 1) / a.nhp_pad);
+  a.magic_hwt = (unsigned)(((1ull << 32) + (16 + 2 * a.p) - 1) / (16 + 2 * a.p));
   const int chunk_bytes = 4 * a.nhp_pad * 16;
   const int nchunks = a.nchunk0 + a.nchunk1;
   const int red_bytes = WK > 1 ? WN * WK * (MT - MT / WK) * NTW * 1024 : 0;   // K-slice exchange buffer

@@ -105,13 +105,9 @@ template <> __device__ __forceinline__ f32x4_t mma_step<NINT_F32>(u32x4_t a, u32
 // div_fmas, div_fixup) and the LSTM epilogue does five per element -- it was half of the epilogue's VALU work.
 __device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
-// tanh through exp; exact to ~2e-7 relative for the |x| range of LSTM pre-activations and
-// saturates cleanly for large |x| (exp underflow -> 0 -> (1 - 0) * rcp(1 + 0) = 1).
-__device__ __forceinline__ float tanhf_(float x) {
-  float e = __expf(-2.0f * fabsf(x));
-  float t = (1.0f - e) * rcpf_(1.0f + e);
-  return copysignf(t, x);
-}
+// tanh(x) = 2*sigmoid(2x) - 1: five instructions (mul, exp, add, rcp, fma); saturates cleanly (exp overflow ->
+// inf -> rcp 0 -> -1; underflow -> 0 -> rcp(1) -> 1); absolute error ~1e-7 (cancellation near 0 is absolute, not relative)
+__device__ __forceinline__ float tanhf_(float x) { return fmaf(2.0f, rcpf_(1.0f + __expf(-2.0f * x)), -1.0f); }
 
 // launcher-side descriptors -----------------------------------------------------------------
 struct ConvArgs {
@@ -129,6 +125,7 @@ struct ConvArgs {
   int cpf;               // channel chunks per LDS A fill
   int a_bytes;           // bytes reserved for the A image
   int nhp_pad;           // halo-tile pixels rounded up to 16 (one g-plane of the A image)
+  unsigned magic_nhpp, magic_hwt;   // ceil(2^32 / nhp_pad), ceil(2^32 / (16 + 2p)): division by multiply-high in the fill
   // LSTM epilogue
   const float* bias;     // [4*Ch16] permuted
   const float* c_prev;   // compact [N][H][W][Chp] or nullptr (= 0)
