@@ -393,21 +393,44 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       }
     }
   } else {
+    // x columns accumulate into (or overwrite) the layer below's dh / dx, h columns are stored to dh_prev.
+    // Addresses = wave-uniform row base + row-invariant lane offset; the read-modify-write loads of ALL rows are
+    // issued before the first store (vmcnt retires in order and counts stores: a load between stores would wait
+    // for the previous row's stores to be acknowledged).
+    const bool rmw = a.out0 && !a.out0_overwrite;
+    constexpr bool HOIST = Q * NTW <= 16;      // (register budget: the widest tiles keep the load inside the row loop)
+    f32x4_t old[HOIST ? Q : 1][HOIST ? NTW : 1];
+#pragma unroll
+    for (int i = 0; i < (HOIST ? Q : 0); ++i) {
+      const int y = y0 + (i + wk * Q) % MT;
+      const size_t rowpix = ((size_t)img * a.H + y) * a.W;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = (nt0 + j) * 16 + c4;
+        old[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (rmw && n < a.C0p && y < a.H && x < a.W)
+          old[i][j] = load_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + n));
+      }
+    }
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
       const int y = y0 + (i + wk * Q) % MT;
       if (y < a.H && x < a.W) {
-        const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+        const size_t rowpix = ((size_t)img * a.H + y) * a.W;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           const int n = (nt0 + j) * 16 + c4;
           if (n < a.C0p) {
             if (a.out0) {
-              const size_t o = pix * a.C0p + n;
-              store_vec4<DT>(a.out0, o, a.out0_overwrite ? acc[i][j] : load_vec4<DT>(a.out0, o) + acc[i][j]);
+              char* row0 = a.out0 + rowpix * a.C0p * Elem<DT>::ES;
+              const unsigned o = (unsigned)(x * a.C0p + n);
+              f32x4_t prev;
+              if constexpr (HOIST) prev = old[i][j];
+              else prev = rmw ? load_vec4<DT>(row0, o) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+              store_vec4<DT>(row0, o, prev + acc[i][j]);
             }
           } else if (a.out1) {
-            store_vec4<DT>(a.out1, pix * a.C1p + (n - a.C0p), acc[i][j]);
+            store_vec4<DT>(a.out1 + rowpix * a.C1p * Elem<DT>::ES, (unsigned)(x * a.C1p + (n - a.C0p)), acc[i][j]);
           }
         }
       }
