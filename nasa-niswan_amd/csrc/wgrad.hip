@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   int vB[JW];
   int vA;
   const int nvalid = __builtin_amdgcn_readfirstlane(min(JW, max(0, a.J - j0)));   // real columns of this wave
+  constexpr int JT = KS * KS * NTCT;                                              // = a.J (host-checked)
+  constexpr int NVL = JT % JW == 0 ? JW : JT % JW;                                // columns of the last, partial group
   if constexpr (DT == NINT_BF16) {
     const int q = i16 >> 2, p8 = (i16 & 3) * 8;
     vA = (4 * g + q) * RA + i0 * 32 + p8;             // pixel 4g+q of a 16-pixel half segment, 8 bytes of 4 channels
@@ -203,12 +205,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
         // the reads above are unconditional (clamped columns); the MFMAs of a column past J are skipped by a
         // wave-uniform branch so that the short wave (25 taps = 7+7+7+4) does not burn matrix-pipe time
+        // A wave has JW, NVL (= the columns left for the last group) or 0 real columns, so two wave-uniform
+        // branches per pixel row cover every case -- one per column would cost 2 SALU instructions each in a
+        // loop that is instruction-issue-bound -- and every MFMA still appears exactly once in the code.
+        if (nvalid > 0) {
 #pragma unroll
-        for (int jj = 0; jj < JW; ++jj) {
-          if (jj < nvalid) {
+          for (int jj = 0; jj < NVL; ++jj)
 #pragma unroll
             for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
-          }
+        }
+        if (nvalid == JW) {
+#pragma unroll
+          for (int jj = NVL; jj < JW; ++jj)
+#pragma unroll
+            for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
         }
       }
     } else {
