@@ -45,22 +45,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   typedef WgTile<DT> TT;
   constexpr int PR = TT::PR, RA = TT::RA;
   constexpr int NTN = 4 / NS;
-  constexpr int A_UNITS_PIX = 64 * E::ES / 16;           // 16-byte units per dG pixel row (64 gate columns)
-  constexpr int A_UNITS = PR * 32 * A_UNITS_PIX;
-  constexpr int A_PER_THR = A_UNITS / 256;
-  static_assert(A_UNITS % 256 == 0, "dG tile must split evenly over the workgroup");
-  constexpr int B_PER_THR_MAX = 5;
+  constexpr int A_UNITS_PIX = 64 * E::ES / 16;           // 16-byte data units per dG pixel row (64 gate columns)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int p = KS / 2, k = KS;
   constexpr int HWt = 32 + 2 * p, HHt = PR + 2 * p;
   constexpr int RB = TT::rb(NTCT);
-  constexpr int b_units_pix = 16 * NTCT * E::ES / 16;    // units per cat halo pixel
-  constexpr int b_units = HHt * HWt * b_units_pix;
+  constexpr int b_units_pix = 16 * NTCT * E::ES / 16;    // data units per cat halo pixel
+  // The two LDS images seen as 16-byte units INCLUDING their row padding: a tile is staged by LDS-DMA
+  // (global_load_lds_dwordx4: 64 consecutive units per wave instruction, per-lane source address), no VGPR
+  // round trip, no ds_write pass; lanes that land on padding re-read the tile's first unit.
+  constexpr int UA_ROW = RA / 16, NA_U = PR * 32 * UA_ROW;
+  constexpr int UB_PIX = RB / 16, NB_U = HHt * HWt * UB_PIX, NB_U_PAD = (NB_U + 63) / 64 * 64;
   constexpr int a_bytes = PR * 32 * RA;
-  constexpr int b_bytes = (HHt * HWt * RB + 15) / 16 * 16;
+  constexpr int b_bytes = NB_U_PAD * 16;
   constexpr int buf_bytes = a_bytes + b_bytes;
+  static_assert(NA_U % 64 == 0 && a_bytes % 1024 == 0, "whole DMA pieces");
+  constexpr int NI_A = NA_U / 64, NI_B = NB_U_PAD / 64, NI = NI_A + NI_B, NI_W = (NI + 3) / 4;
 
   const int nb = blockIdx.y / a.CB, cb = blockIdx.y % a.CB;
   const int t_begin = blockIdx.x * a.tiles_per_split;
@@ -74,24 +77,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < JW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  u32x4_t areg[A_PER_THR], breg[B_PER_THR_MAX];
-
-  // Staging addresses = wave-uniform tile base (SGPRs, advanced incrementally from tile to tile) + a per-thread
-  // 32-bit offset that does not depend on the tile (computed once): the tile loop spends no VALU and no
-  // integer division on addresses -- the loop is instruction-issue-bound, every instruction beside the MFMAs counts.
-  unsigned aoff[A_PER_THR], boff[B_PER_THR_MAX];
+  // Per-lane source offsets of this wave's DMA pieces (piece t = wave + 4*i), relative to the wave-uniform tile
+  // base: they do not depend on the tile, so the tile loop spends no VALU on staging addresses.
+  unsigned doff[NI_W];
 #pragma unroll
-  for (int i = 0; i < A_PER_THR; ++i) {
-    const int u = tid + i * 256;
-    const int q = u % A_UNITS_PIX, pix = u / A_UNITS_PIX;
-    aoff[i] = (unsigned)(((pix >> 5) * a.Wh + (pix & 31)) * a.dG_pix_stride + q * 16);
-  }
-#pragma unroll
-  for (int i = 0; i < B_PER_THR_MAX; ++i) {
-    const int u = min(tid + i * 256, b_units - 1);        // threads past the image re-read its last unit (never written to LDS)
-    const int q = u % b_units_pix, hp = u / b_units_pix;
-    const int hy = hp / HWt, hx = hp - hy * HWt;
-    boff[i] = (unsigned)((hy * a.Wh + hx) * a.src_pix_stride + q * 16);
+  for (int i = 0; i < NI_W; ++i) {
+    const int t = wave + 4 * i;
+    unsigned o = 0;
+    if (t < NI_A) {
+      const int u = t * 64 + lane;
+      const int pix = u / UA_ROW, q = u - pix * UA_ROW;
+      if (q < A_UNITS_PIX) o = (unsigned)(((pix >> 5) * a.Wh + (pix & 31)) * a.dG_pix_stride + q * 16);
+    } else if (t < NI) {
+      const int u = (t - NI_A) * 64 + lane;
+      const int hp = u / UB_PIX, q = u - hp * UB_PIX;
+      const int hy = hp / HWt, hx = hp - hy * HWt;
+      if (hp < HHt * HWt && q < b_units_pix) o = (unsigned)((hy * a.Wh + hx) * a.src_pix_stride + q * 16);
+    }
+    doff[i] = o;
   }
   // tile coordinates of the next tile to load, kept incrementally (tiles of a split are consecutive)
   int ld_tx, ld_ty, ld_img;
@@ -104,43 +107,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const char* const ga0 = a.dG + nb * 64 * E::ES;
   const char* const gb0 = a.src + cb * 16 * NTCT * E::ES;
 
-  auto issue_loads = [&]() {                 // loads tile (ld_img, ld_ty, ld_tx), then steps to the next one
+  auto issue_dma = [&](char* buf) {          // stages tile (ld_img, ld_ty, ld_tx) into buf, then steps to the next tile
     const int y0 = ld_ty * PR, x0 = ld_tx * 32;
     const char* ga = ga0 + (long)ld_img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride;
-#pragma unroll
-    for (int i = 0; i < A_PER_THR; ++i) areg[i] = *(const u32x4_t*)(ga + aoff[i]);
     const char* gb = gb0 + (long)ld_img * a.src_img_stride + ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride;
 #pragma unroll
-    for (int i = 0; i < B_PER_THR_MAX; ++i)
-      if (i * 256 < b_units) breg[i] = *(const u32x4_t*)(gb + boff[i]);
+    for (int i = 0; i < NI_W; ++i) {
+      const int t = wave + 4 * i;              // wave-uniform
+      if (t < NI) {
+        const char* src = (t < NI_A ? ga : gb) + doff[i];
+        char* dst = buf + (t < NI_A ? t * 1024 : a_bytes + (t - NI_A) * 1024);
+        // issued as inline asm ON PURPOSE: hipcc would count the builtin as an LDS write and wait vmcnt(0) ahead
+        // of the next ds_read (it cannot tell the two buffers apart), which makes the staging synchronous; an asm
+        // DMA is invisible to its bookkeeping, so the wait is ours: s_waitcnt vmcnt(0) ahead of the tile's barrier.
+        // (M0 = LDS destination base; saved and restored in the same statement.)
+        unsigned keep;
+        const unsigned lds_dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+      }
+    }
     const bool wx = ld_tx + 1 == a.tiles_x;
     const bool wy = wx && (ld_ty + 1 == a.tiles_y);
     ld_tx = wx ? 0 : ld_tx + 1;
     ld_ty = wy ? 0 : (wx ? ld_ty + 1 : ld_ty);
     ld_img += wy ? 1 : 0;
   };
-  auto write_lds = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < A_PER_THR; ++i) {
-      const int u = tid + i * 256;
-      const int q = u % A_UNITS_PIX, pix = u / A_UNITS_PIX;
-      *(u32x4_t*)(buf + pix * RA + q * 16) = areg[i];
-    }
-    char* bb = buf + a_bytes;
-#pragma unroll
-    for (int i = 0; i < B_PER_THR_MAX; ++i) {
-      const int u = tid + i * 256;
-      if (i * 256 < b_units && u < b_units) {
-        const int q = u % b_units_pix, hp = u / b_units_pix;
-        *(u32x4_t*)(bb + hp * RB + q * 16) = breg[i];
-      }
-    }
-  };
 
-  if (t_begin < t_end) {
-    issue_loads();
-    write_lds(smem);
-  }
+  if (t_begin < t_end) issue_dma(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // lane constants of the transposed reads
@@ -176,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int cur = (tile - t_begin) & 1;
     const bool more = tile + 1 < t_end;
-    if (more) issue_loads();
+    if (more) issue_dma(smem + (cur ^ 1) * buf_bytes);   // the other buffer was last read before the previous barrier
     const char* Ab = smem + cur * buf_bytes + vA;      // one add per base and tile; everything below is base + immediate
     const char* Bb[JW];
 #pragma unroll
@@ -184,30 +179,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     if constexpr (DT == NINT_BF16) {
 #pragma unroll
       for (int pr = 0; pr < PR; ++pr) {
-        // pixel -> K-slot: read rd covers pixels rd*16 + 4*g + q of the 32-pixel row segment
-        u32x4_t af[NTN];
-#pragma unroll
-        for (int i = 0; i < NTN; ++i) {
-          const char* ad = Ab + pr * 32 * RA + i * 32;
+        // pixel -> K-slot: read rd covers pixels rd*16 + 4*g + q of the 32-pixel row segment.  (Double-buffering
+        // the fragments per pixel row -- reads of row pr+1 ahead of the MFMAs of row pr -- was measured: it gives
+        // back what the LDS-DMA staging gained, 236 VGPRs.)
+        auto read_tr = [&](const char* ad, int half) __attribute__((always_inline)) {
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + 16 * RA));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + half));
           u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-          af[i] = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
-        }
-        u32x4_t bf[JW];
+          return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
+        };
+        u32x4_t af[NTN], bf[JW];
 #pragma unroll
-        for (int jj = 0; jj < JW; ++jj) {
-          const char* bd = Bb[jj] + pr * HWt * RB;
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(bd + 16 * RB));
-          u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-          bf[jj] = (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
-        }
-        // the reads above are unconditional (clamped columns); the MFMAs of a column past J are skipped by a
-        // wave-uniform branch so that the short wave (25 taps = 7+7+7+4) does not burn matrix-pipe time
-        // A wave has JW, NVL (= the columns left for the last group) or 0 real columns, so two wave-uniform
-        // branches per pixel row cover every case -- one per column would cost 2 SALU instructions each in a
-        // loop that is instruction-issue-bound -- and every MFMA still appears exactly once in the code.
+        for (int i = 0; i < NTN; ++i) af[i] = read_tr(Ab + pr * 32 * RA + i * 32, 16 * RA);
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) bf[jj] = read_tr(Bb[jj] + pr * HWt * RB, 16 * RB);
+        // The reads are unconditional (clamped columns).  A wave has JW, NVL (= the columns left for the last
+        // group) or 0 real columns, so two wave-uniform branches per pixel row cover every case -- one per column
+        // would cost 2 SALU instructions each -- and every MFMA still appears exactly once in the code.
         if (nvalid > 0) {
 #pragma unroll
           for (int jj = 0; jj < NVL; ++jj)
@@ -246,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
       }
     }
-    if (more) write_lds(smem + (cur ^ 1) * buf_bytes);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed ...
+    __syncthreads();                           // ... for every wave, and this one is fully read
   }
 
   // ---- flush: partial[split][blockIdx.y][j][n'loc 64][c 16]
@@ -423,10 +411,8 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   typedef WgTile<DT> TT;
   const int p = a.p;
   const int a_bytes = TT::PR * 32 * TT::RA;
-  const int b_bytes = nint_round_up((TT::PR + 2 * p) * (32 + 2 * p) * TT::rb(a.NTC), 16);
+  const int b_bytes = nint_round_up((TT::PR + 2 * p) * (32 + 2 * p) * TT::rb(a.NTC), 1024);   // whole 1-KiB DMA pieces
   const size_t lds = 2 * (size_t)(a_bytes + b_bytes);
-  const int b_units = (TT::PR + 2 * p) * (32 + 2 * p) * (16 * a.NTC * Elem<DT>::ES / 16);
-  if (b_units > 5 * 256) return NINT_E_SHAPE;
   if (lds > 160 * 1024) return NINT_E_LDS;
   if (a.k != KS || a.NTC != NTCT) return NINT_E_ARG;
   auto kern = wgrad_kernel<DT, JW, NS, KS, NTCT>;
