@@ -192,8 +192,8 @@ def test_bf16_tracks_f32_along_a_training_trajectory(pkg):
     assert worst_loss <= 1e-2 and worst_cos >= 0.995 and last < 0.97 * first
 
 
-@pytest.mark.parametrize("env", [{"NINT_STREAMS": "1", "NINT_WG_CHUNKS": "2"}, {"NINT_MT": "4"}, {"NINT_MT": "8"}],
-                         ids=["layer-wavefront+chunked-wgrad", "all-4-row-tiles", "all-8-row-tiles"])
+@pytest.mark.parametrize("env", [{"NINT_STREAMS": "1", "NINT_WG_CHUNKS": "2"}, {"NINT_MT": "4"}, {"NINT_MT": "8"}, {"NINT_WG_NS": "2"}],
+                         ids=["layer-wavefront+chunked-wgrad", "all-4-row-tiles", "all-8-row-tiles", "wgrad-2x2-wave-split"])
 def test_opt_in_schedules_and_tile_heights_keep_parity(pkg, env):
     """The launch-shape switches are read once per process, so the model-level parity tests are
     re-run in a child process under each setting: multi-stream layer wavefront with time-chunked weight
