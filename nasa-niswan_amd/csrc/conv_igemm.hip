@@ -483,6 +483,7 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;
+    if (mt_env == 6 && cbs % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 4, 6>(a, N, cbs / 4, st);
     if (cbs % 4 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, cbs / 4, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, cbs / 4, st);
     if (cbs % 2 == 0) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st);
     return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st);

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--H", type=int, default=100)
     ap.add_argument("--W", type=int, default=154)
+    ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (data-dependent power / clock check)")
     ap.add_argument("--split", type=int, default=1, help="issue the forward gate kernel as this many launches over image groups")
     args = ap.parse_args()
     lib = pkg.load_library()
@@ -44,10 +45,10 @@ def main():
     eng = SeqEngine(cfgs, args.dtype, "cuda")
     B, T, H, W = args.batch, args.T, args.H, args.W
     ws = eng.acquire(B, T, H, W, True, False)
-    ws_w = [torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * 0.05 for c in cfgs]
+    ws_w = [torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * (0.0 if args.zeros else 0.05) for c in cfgs]
     ws_b = [torch.zeros(4 * c.Ch, device="cuda") for c in cfgs]
     eng.pack_weights(ws_w, ws_b)
-    X = torch.randn(B, T, args.C, H, W, device="cuda")
+    X = torch.randn(B, T, args.C, H, W, device="cuda") * (0.0 if args.zeros else 1.0)
     eng.forward(ws, X)       # fills every slab with realistic (random-data) values
     for l in range(3):
         ws.dh[l].view(torch.bfloat16 if eng.es == 2 else torch.float32).normal_(); ws.dc[l].normal_()
