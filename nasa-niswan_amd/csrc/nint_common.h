@@ -144,5 +144,8 @@ struct ConvArgs {
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                      float* db_partial, bool dc_zero, void* stream);
+int nint_internal_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
+                                     const void* dG, const void* x_slab, const void* h_slab, float* partial,
+                                     size_t partial_bytes, int n_cu, int h_skip, void* stream);
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
                              void* dh_prev, bool overwrite_dx, void* stream);

@@ -284,9 +284,9 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
         NINT_CHECK_HIP(hipStreamWaitEvent(pool->wg[l], pool->evw[l], 0));
         const char* x_all = (l == 0) ? (const char*)s->xs
                                      : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
-        rc = nint_conv_wgrad_partial(ly, g, s->dtype, N_plan, t * B, (t_hi - t) * B, s->dG[l], x_all, s->h[l],
-                                     (float*)((char*)s->wg_partial + wg_off[l] + (size_t)c * wg_stride[l]), wg_stride[l],
-                                     s->n_cu, pool->wg[l]);
+        rc = nint_internal_conv_wgrad_partial(ly, g, s->dtype, N_plan, t * B, (t_hi - t) * B, s->dG[l], x_all, s->h[l],
+                                              (float*)((char*)s->wg_partial + wg_off[l] + (size_t)c * wg_stride[l]), wg_stride[l],
+                                              s->n_cu, (t == 0 && !s->has_init_state) ? B : 0, pool->wg[l]);
         if (rc != NINT_OK) return rc;
       }
     }
@@ -308,9 +308,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // with the layer wavefront the three launches run concurrently: each layer has its own workspace
       float* part = wave ? (float*)((char*)s->wg_partial + wg_off[l]) : s->wg_partial;
       const size_t part_bytes = wave ? wg_stride[l] : s->wg_partial_bytes;
-      rc = nint_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
-                           part, part_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
-                           s->T * NINT_DB_ROWS, S[l]);
+      // h_{-1} = 0 for a sequence from the zero state: the h part of the reduction skips time step 0
+      rc = nint_internal_conv_wgrad_partial(ly, g, s->dtype, s->T * B, 0, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */,
+                                            part, part_bytes, s->n_cu, s->has_init_state ? 0 : B, S[l]);
+      if (rc != NINT_OK) return rc;
+      rc = nint_conv_wgrad_finalize(ly, g, s->dtype, s->T * B, 1, 0, s->T * B, s->dG[l], s->dW[l], s->db[l], part, s->n_cu,
+                                    fused_db ? s->db_partial[l] : nullptr, s->T * NINT_DB_ROWS, S[l]);
       if (rc != NINT_OK) return rc;
     }
   }

@@ -446,6 +446,15 @@ static int dispatch_wgrad(WgradArgs& a, const WgPlan& pl, int splits, int nblk, 
 extern "C" int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
                                        const void* dG, const void* x_slab, const void* h_slab, float* partial,
                                        size_t partial_bytes, int n_cu, void* stream) {
+  return nint_internal_conv_wgrad_partial(ly, g, dtype, N_plan, n_first, N, dG, x_slab, h_slab, partial, partial_bytes, n_cu, 0, stream);
+}
+
+// h_skip: the first h_skip images of this chunk have an identically zero h source (h_{-1} = 0 of a sequence that
+// starts from the zero state, model.py:259-262): the h part skips them -- 1/T of its work.
+int nint_internal_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
+                                     const void* dG, const void* x_slab, const void* h_slab, float* partial,
+                                     size_t partial_bytes, int n_cu, int h_skip, void* stream) {
+  if (h_skip < 0 || h_skip > N) return NINT_E_ARG;
   if (!ly || !g || !dG || !x_slab || !h_slab || !partial || N <= 0 || N_plan < N || n_first < 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   WgPlan pl;
@@ -459,20 +468,21 @@ extern "C" int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g,
     WgradArgs a = {};
     a.dG_pix_stride = Gc * es;
     a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
-    a.dG = (const char*)dG + (size_t)n_first * a.dG_img_stride;
+    const int skip = part == 1 ? h_skip : 0;
+    a.dG = (const char*)dG + (size_t)(n_first + skip) * a.dG_img_stride;
     const int Cp = part == 0 ? ly->Cxp : ly->Chp;
     a.src_pix_stride = Cp * es;
     a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
-    a.src = (const char*)(part == 0 ? x_slab : h_slab) + (size_t)n_first * a.src_img_stride;
+    a.src = (const char*)(part == 0 ? x_slab : h_slab) + (size_t)(n_first + skip) * a.src_img_stride;
     a.partial = partial + (part == 0 ? 0 : pl.off_h);
     a.CB = part == 0 ? pl.CBx : pl.CBh;
     a.NTC = pl.NTC; a.J = pl.J;
     a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
     a.P = g->P; a.Wh = g->Wh;
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
-    a.ntiles = N * pl.tiles_x * pl.tiles_y;           // this chunk; later splits may be empty (they flush zeros)
-    a.tiles_per_split = part == 0 ? pl.tps_x : pl.tps_h;
+    a.ntiles = (N - skip) * pl.tiles_x * pl.tiles_y;  // this chunk; empty splits flush zeros
     const int splits = part == 0 ? pl.splits_x : pl.splits_h;
+    a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, splits) : 1;   // spread what is there evenly over the planned splits
     const int nblk = pl.NB * a.CB;
     rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, pl, splits, nblk, st) : dispatch_wgrad<NINT_F32>(a, pl, splits, nblk, st);
     if (rc != NINT_OK) return rc;
