@@ -80,7 +80,7 @@ def main():
             for part in range(args.split):      # image groups: every slab pointer advances by the group's images
                 f = part * nb
                 assert lib.nint_cell_fwd(C.byref(ly), g, eng.dt, nb if part < args.split - 1 else B - f,
-                                         C.c_void_p(xs + f * (xs_img := halo_px * ly.Cxp * es)),
+                                         C.c_void_p(xs + f * halo_px * ly.Cxp * es),
                                          C.c_void_p(ws.h[l].data_ptr() + hs + f * halo_px * ly.Chp * es),
                                          C.c_void_p(ws.c[l].data_ptr() + cs + f * comp_px * ly.Chp * 4),
                                          C.c_void_p(ws.h[l].data_ptr() + 2 * hs + f * halo_px * ly.Chp * es),
