@@ -72,9 +72,10 @@ def test_shapes_vs_oracle(pkg, name, dtype):
 
 
 def test_full_size_properties(pkg):
-    """100x154 padded grid, T=12, C=62, out=20 (the bench workload) at B=2: the oracle needs minutes
-    here, so check what must hold at any size: run-to-run bitwise determinism, batch independence
-    (a sample's result does not depend on its batch mates) and agreement of the f32 and bf16 paths."""
+    """100x154 padded grid, T=12, C=62, out=20 (the bench workload) at B=2: size-independent properties
+    on top of the oracle comparison at this size (tests/test_gpu_fullsize.py): run-to-run bitwise
+    determinism, batch independence (a sample's result does not depend on its batch mates) and
+    agreement of the f32 and bf16 paths."""
     torch.manual_seed(0)
     C, hidden, ks, out, B, T, H, W = 62, [64, 32, 16], [5, 3, 3], 20, 2, 12, 100, 154
     X = torch.randn(B, T, C, H, W, device="cuda")
