@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 103
+#define NINT_VERSION 104
 #define NINT_DB_ROWS 1024   /* rows of bias-gradient partials one fused pointwise-backward launch writes */
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
@@ -187,9 +187,12 @@ int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, con
 /* pred (N,O,H,W) f32, y (N,O,Hc,Wc) f32; crop window [oy,oy+Hc) x [ox,ox+Wc).
  * loss_out: NINT_LOSS_SCRATCH_FLOATS floats, 8-byte aligned; [0] = mean((y-p)^2) + mean(|y-p|), the
  * rest is reduction scratch; dpred (N,O,H,W) = d loss / d pred (0 outside the
- * crop), may be NULL; stats (5 doubles, accumulated, caller zeroes): sum (y-p)^2, sum |y-p|,
- * sum y, sum y^2, count -- the device-side R2 accumulators replacing train.py:113-114. */
+ * crop), may be NULL; stats (NINT_LOSS_STATS doubles, accumulated, caller zeroes): [0..4] pooled sums
+ * sum (y-p)^2, sum |y-p|, sum y, sum y^2, count; [5..7] the reference's per-batch statistics: sum over calls
+ * of the loss, sum over calls of sklearn-style r2_score(y, pred) of that call, number of calls -- the
+ * device-side accumulators replacing loss.item() / r2_score(...cpu()) of train.py:113-117, utils.py:73-75. */
 #define NINT_LOSS_SCRATCH_FLOATS 2050
+#define NINT_LOSS_STATS 8
 int nint_loss_mse_l1_crop(const float* pred, const float* y, float* dpred, float* loss_out, double* stats,
                           int N, int O, int H, int W, int oy, int ox, int Hc, int Wc, void* stream);
 
@@ -200,14 +203,33 @@ int nint_adam_flat(float* p, const float* g, float* m, float* v, size_t n, doubl
                    double beta2, double eps, int step, float grad_scale, void* stream);
 
 /* ---- preproc (dataset.py:520-536, 61-98) --------------------------------------------------------- */
-/* srcs: host array of nsrc device pointers, each (T, lev_i, H, W) f32 with lev[i] levels
- * (u,v,omega at L levels, prec and emission at 1) -> out (T, C=sum lev, Hp, Wp) f32:
- * fuse on the channel axis, z-score with mean/std (C floats, device), cyclic-lon + lat halo.
+/* Fuse on the channel axis, z-score with mean/std (C = sum lev floats, device), cyclic-lon + lat halo pad.
  * mode 0 = the committed reference behaviour (np.fliplr on the channel axis, dataset.py:96),
- * mode 1 = true latitude reflect (dataset.py:51 semantics). */
+ * mode 1 = true latitude reflect (dataset.py:51 semantics).
+ * srcs: host array of nsrc device pointers; lev: host array of levels per source (u,v,omega at L levels,
+ * prec and emission at 1).
+ *
+ * nint_preproc_fuse_pad      : ONE sample; srcs[i] points at the window's first time step, (T, lev_i, H, W) f32
+ *                              -> out (T, C, Hp, Wp) f32   (the Dataset.__getitem__ result, dataset.py:538-539).
+ * nint_preproc_fuse_pad_batch: B samples in one launch; srcs[i] is the whole RECORD (n_steps, lev_i, H, W) and
+ *                              sample b reads the time steps [t0[b], t0[b]+T) (the sliding window of
+ *                              dataset.py:614-616 as a pointer offset) -> out (B, T, C, Hp, Wp) f32.
+ * nint_preproc_fuse_pad_slab : the same B windows written STRAIGHT into the model's input halo slab
+ *                              (image t*B+b, ET = dtype, channels-last, channel padding zeroed) on the padded
+ *                              grid g->H x g->W = Hp x Wp: the f32 NCHW tensor of dataset.py:538 and the
+ *                              nint_pack_btchw pass never exist.  Values are the f32 result rounded once to ET.
+ * t0: host array of B non-negative window starts. */
+#define NINT_PRE_MAX_B 64   /* samples per launch (larger batches are split internally) */
 int nint_preproc_fuse_pad(const float* const* srcs /*host*/, const int* lev /*host*/, int nsrc,
                           const float* mean, const float* std, float* out, int T, int H, int W,
                           int Hp, int Wp, int mode, void* stream);
+int nint_preproc_fuse_pad_batch(const float* const* srcs /*host*/, const int* lev /*host*/, int nsrc,
+                                const float* mean, const float* std, const int* t0 /*host*/, int B, float* out,
+                                int T, int H, int W, int Hp, int Wp, int mode, void* stream);
+int nint_preproc_fuse_pad_slab(const float* const* srcs /*host*/, const int* lev /*host*/, int nsrc,
+                               const float* mean, const float* std, const int* t0 /*host*/, int B, void* xs_slab,
+                               int Cxp, int T, int H, int W, const nint_geom* g /*host*/, int mode, int dtype,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("NINT_LIB", os.path.join(HERE, "libnint_hip.so"))   # 
 NINT_F32, NINT_BF16 = 0, 1
 NINT_MAX_LAYERS = 8
 NINT_LOSS_SCRATCH_FLOATS = 2050
+NINT_LOSS_STATS = 8
 NINT_DB_ROWS = 1024
 NINT_WGRAD_CHUNKS = 4
 
@@ -69,6 +70,8 @@ SIGNATURES = {
     "nint_loss_mse_l1_crop": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, _I, _I, _I, _I, vp]),
     "nint_adam_flat": (_I, [vp, vp, vp, vp, _SZ, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, vp]),
     "nint_preproc_fuse_pad": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, vp, _I, _I, _I, _I, _I, _I, vp]),
+    "nint_preproc_fuse_pad_batch": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, C.POINTER(_I), _I, vp, _I, _I, _I, _I, _I, _I, vp]),
+    "nint_preproc_fuse_pad_slab": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, C.POINTER(_I), _I, vp, _I, _I, _I, _I, _PG, _I, _I, vp]),
 }
 
 _lib = None
@@ -92,7 +95,7 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nint_version() != 103:
+    if lib.nint_version() != 104:
         raise NintError("libnint_hip.so version mismatch")
     _lib = lib
     return lib

@@ -702,9 +702,15 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const double* __restric
   }
   if (threadIdx.x == 0) {
     const double s0 = red[0][0], s1 = red[1][0], s2 = red[2][0], s3 = red[3][0];
-    if (loss_out) loss_out[0] = (float)(s0 / count + s1 / count);
+    const double loss = s0 / count + s1 / count;
+    if (loss_out) loss_out[0] = (float)loss;
     if (stats) {
       stats[0] += s0; stats[1] += s1; stats[2] += s2; stats[3] += s3; stats[4] += count;
+      // the reference's per-batch statistics (train.py:113-117, utils.py:73-75): it sums loss.item() and
+      // sklearn r2_score(y, pred) of every batch and divides by the number of batches
+      const double ss_tot = s3 - s2 * s2 / count;
+      const double r2 = ss_tot > 0.0 ? 1.0 - s0 / ss_tot : (s0 == 0.0 ? 1.0 : 0.0);   // sklearn's constant-target convention
+      stats[5] += loss; stats[6] += r2; stats[7] += 1.0;
     }
   }
 }
@@ -769,68 +775,212 @@ extern "C" int nint_adam_flat(float* p, const float* g, float* m, float* v, size
 //        bottom halo row j      <- source row H-pb-1+j  (mode 0, channel C-1-c) / H-2-j (mode 1)
 //   value = (src - mean[c]) / std[c]                              (dataset.py:528), with mean/std of
 //   the SOURCE channel that is actually read (the reference z-scores before it pads).
+// Sources are RECORDS (n_steps, lev_i, H, W) resident in HBM; sample b of a batch reads the time steps
+// [t0[b], t0[b]+T) of every source (the sliding window of dataset.py:614-616 as a pointer offset), so one
+// launch serves the whole batch.  All index arithmetic is per row (scalar); threads only walk x.
 #define PRE_MAX_SRC 16
+#define PRE_MAX_B NINT_PRE_MAX_B
 struct PreArgs {
   const float* src[PRE_MAX_SRC];
   int first_c[PRE_MAX_SRC + 1];   // first fused channel of each source
   int nsrc;
+  int t0[PRE_MAX_B];              // first time step of each sample's window
 };
 
-__global__ void preproc_kernel(PreArgs a, const float* __restrict__ mean, const float* __restrict__ stdv,
-                               float* __restrict__ out, int T, int C, int H, int W, int Hp, int Wp, int mode) {
-  const int pl = (Wp - W) / 2;
-  const int pt = (Hp - H) / 2;
-  const int pb = Hp - H - pt;
-  const size_t total = (size_t)T * C * Hp * Wp;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int xp = i % Wp;
-    size_t r = i / Wp;
-    const int yp = r % Hp; r /= Hp;
-    int c = r % C;
-    const int t = r / C;
-    int xs = xp - pl;
-    if (xs < 0) xs += W;
-    else if (xs >= W) xs -= W;
-    int ys;
-    if (yp < pt) {
-      if (mode == 0) { ys = 1 + yp; c = C - 1 - c; }
-      else ys = pt - yp;
-    } else if (yp < pt + H) {
-      ys = yp - pt;
-    } else {
-      const int j = yp - pt - H;
-      if (mode == 0) { ys = H - pb - 1 + j; c = C - 1 - c; }
-      else ys = H - 2 - j;
-    }
-    int s = 0;
-    while (s + 1 < a.nsrc && c >= a.first_c[s + 1]) ++s;
-    const int lev = c - a.first_c[s];
-    const int nlev = a.first_c[s + 1] - a.first_c[s];
-    const float v = a.src[s][(((size_t)t * nlev + lev) * H + ys) * W + xs];
-    out[i] = (v - mean[c]) / stdv[c];
+// latitude rule: source row of padded row yp, and whether the row comes from the channel-flipped source
+__device__ __forceinline__ int pre_src_row(int yp, int H, int pt, int pb, int mode, bool* flip) {
+  *flip = false;
+  if (yp < pt) {
+    if (mode == 0) { *flip = true; return 1 + yp; }
+    return pt - yp;
   }
+  if (yp < pt + H) return yp - pt;
+  const int j = yp - pt - H;
+  if (mode == 0) { *flip = true; return H - pb - 1 + j; }
+  return H - 2 - j;
+}
+
+// (source, level) of fused channel c: wave-uniform, a handful of scalar compares
+__device__ __forceinline__ void pre_find(const PreArgs& a, int c, int* s_out, int* lev_out, int* nlev_out) {
+  int s = 0;
+  while (s + 1 < a.nsrc && c >= a.first_c[s + 1]) ++s;
+  *s_out = s;
+  *lev_out = c - a.first_c[s];
+  *nlev_out = a.first_c[s + 1] - a.first_c[s];
+}
+
+// f32 NCHW output (B, T, C, Hp, Wp): one workgroup per (b, t, c) plane and row group; the public
+// Dataset.__getitem__ layout (dataset.py:538-539) and the target z-score.
+__global__ __launch_bounds__(256) void preproc_nchw_kernel(PreArgs a, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                           float* __restrict__ out, int B, int T, int C, int H, int W, int Hp,
+                                                           int Wp, int mode) {
+  const int pl = (Wp - W) / 2, pt = (Hp - H) / 2, pb = Hp - H - pt;
+  int r = blockIdx.x;
+  const int c = r % C; r /= C;
+  const int t = r % T;
+  const int b = r / T;
+  // the two candidate source channels of this plane (interior rows: c, mode-0 halo rows: C-1-c)
+  const float* base[2]; float m[2], sd[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int cs = f ? C - 1 - c : c;
+    int s, lev, nlev;
+    pre_find(a, cs, &s, &lev, &nlev);
+    base[f] = a.src[s] + ((size_t)(a.t0[b] + t) * nlev + lev) * H * W;
+    m[f] = mean[cs]; sd[f] = stdv[cs];
+  }
+  float* o = out + (((size_t)b * T + t) * C + c) * Hp * Wp;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int yp = blockIdx.y * 4 + wave; yp < Hp; yp += gridDim.y * 4) {      // a wave per row: row math is scalar
+    bool flip;
+    const int ys = pre_src_row(yp, H, pt, pb, mode, &flip);
+    const float* row = base[flip ? 1 : 0] + (size_t)ys * W;
+    const float mm = flip ? m[1] : m[0], ss = flip ? sd[1] : sd[0];
+    for (int xp = lane; xp < Wp; xp += 64) {
+      int xs = xp - pl;
+      xs = xs < 0 ? xs + W : (xs >= W ? xs - W : xs);
+      o[(size_t)yp * Wp + xp] = (row[xs] - mm) / ss;
+    }
+  }
+}
+
+// Straight into the model's input halo slab: image t*B + b0 + b, interior rows/columns [P, P+Hp) x [P, P+Wp),
+// channels-last ET with the channel padding written as zeros.  One workgroup per (b, t, yp) row: the C source
+// rows (each contiguous along x) are z-scored into an LDS tile [C][W+1], then written out as 16-byte vectors of
+// 8 (bf16) / 4 (f32) consecutive channels -- the f32 NCHW intermediate and the separate pack pass never exist.
+template <int DT>
+__global__ __launch_bounds__(256) void preproc_slab_kernel(PreArgs a, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                           void* __restrict__ dst, int B, int b0, int nb, int T, int C, int Cp,
+                                                           int H, int W, int Hp, int Wp, int mode, int P, int Hh, int Wh) {
+  extern __shared__ float tile[];              // [C][W + 1]
+  const int ld = W + 1;
+  const int pl = (Wp - W) / 2, pt = (Hp - H) / 2, pb = Hp - H - pt;
+  int r = blockIdx.x;
+  const int yp = r % Hp; r /= Hp;
+  const int t = r % T;
+  const int b = r / T;                         // sample inside this launch, [0, nb)
+  bool flip;
+  const int ys = pre_src_row(yp, H, pt, pb, mode, &flip);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int s = 0; s < a.nsrc; ++s) {
+    const int nlev = a.first_c[s + 1] - a.first_c[s];
+    const float* plane0 = a.src[s] + ((size_t)(a.t0[b] + t) * nlev) * H * W + (size_t)ys * W;
+    for (int lev = wave; lev < nlev; lev += 4) {          // a wave per source row
+      const int cs = a.first_c[s] + lev;
+      const int co = flip ? C - 1 - cs : cs;              // output channel fed by this source channel
+      const float mm = mean[cs], ss = stdv[cs];
+      const float* row = plane0 + (size_t)lev * H * W;
+      float* trow = tile + co * ld;
+      for (int x = lane; x < W; x += 64) trow[x] = (row[x] - mm) / ss;
+    }
+  }
+  __syncthreads();
+  constexpr int V = 16 / Elem<DT>::ES;         // channels per 16-byte vector
+  const int nv = Cp / V;
+  char* d = (char*)dst + ((((size_t)t * B + b0 + b) * Hh + (yp + P)) * Wh + P) * (size_t)Cp * Elem<DT>::ES;
+  for (int i = threadIdx.x; i < Wp * nv; i += 256) {
+    const int xp = i / nv, v = i - xp * nv;
+    int xs = xp - pl;
+    xs = xs < 0 ? xs + W : (xs >= W ? xs - W : xs);
+    float f[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = v * V + j;
+      f[j] = c < C ? tile[c * ld + xs] : 0.f;
+    }
+    u32x4_t o;
+    if constexpr (DT == NINT_BF16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(uint32_t, f[j]);
+    }
+    *(u32x4_t*)(d + ((size_t)xp * Cp + v * V) * Elem<DT>::ES) = o;
+  }
+}
+
+static int pre_args(PreArgs* a, const float* const* srcs, const int* lev, int nsrc, int H, int W, int Hp, int Wp, int mode) {
+  if (!srcs || !lev || nsrc <= 0 || nsrc > PRE_MAX_SRC) return NINT_E_ARG;
+  if (Hp < H || Wp < W || (mode != 0 && mode != 1)) return NINT_E_ARG;
+  const int pl = (Wp - W) / 2, pr = Wp - W - pl, pt = (Hp - H) / 2, pb = Hp - H - pt;
+  // the reference raises AttributeError for oversize padding (dataset.py:80,98)
+  if (pl > W || pr > W || pt + 1 > H || pb + 1 > H) return NINT_E_SHAPE;
+  a->nsrc = nsrc;
+  int c = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (!srcs[i] || lev[i] <= 0) return NINT_E_ARG;
+    a->src[i] = srcs[i];
+    a->first_c[i] = c;
+    c += lev[i];
+  }
+  a->first_c[nsrc] = c;
+  return c;
+}
+
+extern "C" int nint_preproc_fuse_pad_batch(const float* const* srcs, const int* lev, int nsrc, const float* mean,
+                                           const float* stdv, const int* t0, int B, float* out, int T, int H, int W,
+                                           int Hp, int Wp, int mode, void* stream) {
+  if (!mean || !stdv || !out || !t0 || T <= 0 || B <= 0) return NINT_E_ARG;
+  PreArgs a;
+  const int C = pre_args(&a, srcs, lev, nsrc, H, W, Hp, Wp, mode);
+  if (C < 0) return C;
+  for (int b0 = 0; b0 < B; b0 += PRE_MAX_B) {
+    const int nb = B - b0 < PRE_MAX_B ? B - b0 : PRE_MAX_B;
+    for (int i = 0; i < nb; ++i) {
+      if (t0[b0 + i] < 0) return NINT_E_ARG;
+      a.t0[i] = t0[b0 + i];
+    }
+    const int planes = nb * T * C;
+    // enough row groups per plane to put a few thousand workgroups in flight on small batches
+    int gy = planes >= 2048 ? 1 : nint_cdiv(2048, planes);
+    if (gy > nint_cdiv(Hp, 4)) gy = nint_cdiv(Hp, 4);
+    hipLaunchKernelGGL(preproc_nchw_kernel, dim3(planes, gy), dim3(256), 0, (hipStream_t)stream, a, mean, stdv,
+                       out + (size_t)b0 * T * C * Hp * Wp, nb, T, C, H, W, Hp, Wp, mode);
+    NINT_LAUNCH_CHECK();
+  }
+  return NINT_OK;
 }
 
 extern "C" int nint_preproc_fuse_pad(const float* const* srcs, const int* lev, int nsrc, const float* mean,
                                      const float* stdv, float* out, int T, int H, int W, int Hp, int Wp, int mode,
                                      void* stream) {
-  if (!srcs || !lev || nsrc <= 0 || nsrc > PRE_MAX_SRC || !mean || !stdv || !out || T <= 0) return NINT_E_ARG;
-  if (Hp < H || Wp < W || (mode != 0 && mode != 1)) return NINT_E_ARG;
-  const int pl = (Wp - W) / 2, pr = Wp - W - pl, pt = (Hp - H) / 2, pb = Hp - H - pt;
-  // the reference raises AttributeError for oversize padding (dataset.py:80,98)
-  if (pl > W || pr > W || pt + 1 > H || pb + 1 > H) return NINT_E_SHAPE;
+  const int t0 = 0;     // srcs already point at the window's first time step
+  return nint_preproc_fuse_pad_batch(srcs, lev, nsrc, mean, stdv, &t0, 1, out, T, H, W, Hp, Wp, mode, stream);
+}
+
+extern "C" int nint_preproc_fuse_pad_slab(const float* const* srcs, const int* lev, int nsrc, const float* mean,
+                                          const float* stdv, const int* t0, int B, void* xs_slab, int Cxp, int T, int H,
+                                          int W, const nint_geom* g, int mode, int dtype, void* stream) {
+  if (!mean || !stdv || !xs_slab || !t0 || !g || T <= 0 || B <= 0) return NINT_E_ARG;
+  if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
+  const int Hp = g->H, Wp = g->W;               // the model runs on the padded grid (launcher.sh:24)
   PreArgs a;
-  a.nsrc = nsrc;
-  int c = 0;
-  for (int i = 0; i < nsrc; ++i) {
-    if (!srcs[i] || lev[i] <= 0) return NINT_E_ARG;
-    a.src[i] = srcs[i];
-    a.first_c[i] = c;
-    c += lev[i];
+  const int C = pre_args(&a, srcs, lev, nsrc, H, W, Hp, Wp, mode);
+  if (C < 0) return C;
+  if (Cxp < C || Cxp % (dtype == NINT_BF16 ? 8 : 4)) return NINT_E_ARG;
+  if ((((uintptr_t)xs_slab) & 15) != 0) return NINT_E_ALIGN;
+  const size_t tile_bytes = (size_t)C * (W + 1) * sizeof(float);
+  if (tile_bytes > 160 * 1024) return NINT_E_LDS;
+  hipStream_t st = (hipStream_t)stream;
+  for (int b0 = 0; b0 < B; b0 += PRE_MAX_B) {
+    const int nb = B - b0 < PRE_MAX_B ? B - b0 : PRE_MAX_B;
+    for (int i = 0; i < nb; ++i) {
+      if (t0[b0 + i] < 0) return NINT_E_ARG;
+      a.t0[i] = t0[b0 + i];
+    }
+    const dim3 grid((unsigned)((size_t)nb * T * Hp));
+#define NINT_PRE(DT_)                                                                                                     \
+    {                                                                                                                     \
+      auto kern = preproc_slab_kernel<DT_>;                                                                               \
+      if (tile_bytes > 64 * 1024)                                                                                         \
+        NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes)); \
+      hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, a, mean, stdv, xs_slab, B, b0, nb, T, C, Cxp, H, W, Hp, Wp, \
+                         mode, g->P, g->Hh, g->Wh);                                                                        \
+    }
+    if (dtype == NINT_BF16) NINT_PRE(NINT_BF16) else NINT_PRE(NINT_F32)
+#undef NINT_PRE
+    NINT_LAUNCH_CHECK();
   }
-  a.first_c[nsrc] = c;
-  const size_t total = (size_t)T * c * Hp * Wp;
-  hipLaunchKernelGGL(preproc_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, a, mean, stdv, out, T, c, H, W, Hp, Wp, mode);
-  NINT_LAUNCH_CHECK();
   return NINT_OK;
 }

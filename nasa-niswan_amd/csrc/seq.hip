@@ -136,6 +136,11 @@ static int pool_get(StreamPool** out) {
   return NINT_OK;
 }
 
+static bool wavefront_env() {   // EXPERIMENT
+  static const bool v = [] { const char* e = getenv("NINT_WAVEFRONT"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 static int seq_check(const nint_seq* s) {
   if (!s || s->L < 1 || s->L > NINT_MAX_LAYERS || s->B < 1 || s->T < 1) return NINT_E_ARG;
   if (s->dtype != NINT_F32 && s->dtype != NINT_BF16) return NINT_E_ARG;
@@ -178,7 +183,7 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   const size_t es = esize(s->dtype);
   const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
   const int B = s->B, L = s->L;
-  const bool multi = pool->enabled && L > 1;
+  const bool multi = pool->enabled && L > 1 && wavefront_env();
   hipStream_t S[NINT_MAX_LAYERS];
   rc = fork_streams(pool, (hipStream_t)stream, S, L, multi);
   if (rc != NINT_OK) return rc;
@@ -241,9 +246,9 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   nch = nint_cdiv(s->T, chunk_steps);
   const int N_plan = chunk_steps * B;
   hipStream_t S[NINT_MAX_LAYERS];
-  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi && L > 1);
+  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi && L > 1 && wavefront_env());
   if (rc != NINT_OK) return rc;
-  const bool wave = multi && L > 1;                       // layer wavefront on side streams
+  const bool wave = multi && L > 1 && wavefront_env();    // layer wavefront on side streams
 
   for (int t = s->T - 1; t >= 0; --t) {
     for (int l = L - 1; l >= 0; --l) {

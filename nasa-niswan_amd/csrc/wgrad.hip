@@ -374,10 +374,11 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   pl->tiles_y = g ? nint_cdiv(g->H, PR) : 1;
   pl->ntiles = g ? N * pl->tiles_x * pl->tiles_y : (1 << 30);
   if (n_cu <= 0) n_cu = 256;
+  static const int occ_env = [] { const char* e = getenv("NINT_WG_OCC"); return e ? atoi(e) : 2; }();   // EXPERIMENT
   auto splits_for = [&](int CB) {
     // two workgroups per CU in flight, but never fewer than 32 pixel tiles per split: the
     // accumulator flush (J KiB-tiles per workgroup) must stay small against the K work
-    int s = nint_cdiv(2 * n_cu, pl->NB * CB);
+    int s = nint_cdiv(occ_env * n_cu, pl->NB * CB);
     if (s > pl->ntiles / 32) s = pl->ntiles / 32;
     if (s < 1) s = 1;
     return s;
@@ -412,7 +413,9 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   const int p = a.p;
   const int a_bytes = TT::PR * 32 * TT::RA;
   const int b_bytes = nint_round_up((TT::PR + 2 * p) * (32 + 2 * p) * TT::rb(a.NTC), 1024);   // whole 1-KiB DMA pieces
-  const size_t lds = 2 * (size_t)(a_bytes + b_bytes);
+  size_t lds = 2 * (size_t)(a_bytes + b_bytes);
+  static const int occ_env = [] { const char* e = getenv("NINT_WG_OCC"); return e ? atoi(e) : 2; }();   // EXPERIMENT
+  if (occ_env == 1 && lds < 82 * 1024) lds = 82 * 1024;   // one workgroup per CU: leave room for the BPTT chain
   if (lds > 160 * 1024) return NINT_E_LDS;
   if (a.k != KS || a.NTC != NTCT) return NINT_E_ARG;
   auto kern = wgrad_kernel<DT, JW, NS, KS, NTCT>;

@@ -134,6 +134,9 @@ class SeqEngine:
             # split-K workspaces: one per layer and time chunk (256-byte aligned), so that the weight-gradient
             # launches of different layers / chunks may overlap with each other and with the rest of BPTT
             wg_bytes += _lib.NINT_WGRAD_CHUNKS * ((self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256)
+        # shapes the weight-gradient kernel has no instantiation for: known NOW, reported at the first training
+        # workspace (forward / inference work for every odd k) instead of as a shape error in the first backward()
+        self.train_unsupported = self.untrainable_layers(self.cfgs, self.dt, self.n_cu)
         self._wg_bytes = wg_bytes
         self._wg_partial = None
         self.pool: Dict[tuple, List[Workspace]] = {}
@@ -160,8 +163,29 @@ class SeqEngine:
             check(self.lib.nint_pack_weights(ptr(W), ptr(b), ptr(self.Wf[l]), ptr(self.Wd[l]), ptr(self.bias_p[l]),
                                              cfg.Cx, cfg.Ch, cfg.k, self.dt, st), "nint_pack_weights")
 
+    @staticmethod
+    def untrainable_layers(cfgs: Sequence[LayerCfg], dtype, n_cu: int = 256) -> List[str]:
+        """Layers whose weight gradient no kernel instantiation covers (`nint_wgrad_workspace_bytes` == 0):
+        kernel sizes other than 1, 3, 5, or more (tap, channel-tile) columns than one workgroup holds.  Pure host
+        arithmetic -- callable without a GPU."""
+        lib = _lib.load()
+        dt = dtype_code(dtype)
+        kc = lib.nint_kc(dt)
+        bad = []
+        for l, cfg in enumerate(cfgs):
+            ly = NintLayer()
+            ly.Cx, ly.Ch, ly.k = cfg.Cx, cfg.Ch, cfg.k
+            ly.Cxp, ly.Ch16, ly.Chp = cfg.padded(kc)
+            if lib.nint_wgrad_workspace_bytes(C.byref(ly), dt, n_cu) == 0:
+                bad.append(f"layer {l} (Cin={cfg.Cx}, Ch={cfg.Ch}, k={cfg.k})")
+        return bad
+
     # ------------------------------------------------------------------ workspaces
     def acquire(self, B, T, H, W, train: bool, has_init: bool) -> Workspace:
+        if train and self.train_unsupported:
+            raise _lib.NintError("training is not supported for " + ", ".join(self.train_unsupported) + ": the weight-gradient "
+                                 "kernel is instantiated for kernel sizes 1, 3 and 5 only (the reference accepts any odd k, "
+                                 "model.py:204); forward / inference (torch.no_grad()) work for every odd k")
         key = (B, T, H, W, train, has_init)
         for ws in self.pool.setdefault(key, []):
             if not ws.in_use:
@@ -181,15 +205,20 @@ class SeqEngine:
     # ------------------------------------------------------------------ passes
     def forward(self, ws: Workspace, x: torch.Tensor, h0: Optional[List[torch.Tensor]] = None,
                 c0: Optional[List[torch.Tensor]] = None):
-        """x (B,T,C,H,W) f32 on the engine's device.  Runs model.py:253-271 (all layers, all steps)."""
+        """x (B,T,C,H,W) f32 on the engine's device, or a dataset.SlabBatch of that shape.  Runs model.py:253-271
+        (all layers, all steps)."""
         B, T, Cc, H, W = x.shape
         assert (B, T, H, W) == (ws.B, ws.T, ws.H, ws.W) and Cc == self.cfgs[0].Cx
-        x = x.detach()
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
         st = stream_ptr()
         g = C.byref(ws.g)
-        check(self.lib.nint_pack_btchw(ptr(x), ptr(ws.xs), B, T, Cc, ws.Cxp0, g, self.dt, st), "nint_pack_btchw")
+        if hasattr(x, "fill_slab"):
+            # an un-materialised batch (dataset.SlabBatch): the preproc kernel writes the input slab directly
+            x.fill_slab(self, ws)
+        else:
+            x = x.detach()
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                x = x.float().contiguous()
+            check(self.lib.nint_pack_btchw(ptr(x), ptr(ws.xs), B, T, Cc, ws.Cxp0, g, self.dt, st), "nint_pack_btchw")
         if h0 is not None:
             for l, cfg in enumerate(self.cfgs):
                 Chp = cfg.padded(self.kc)[2]

@@ -4,7 +4,11 @@ MI355X step.  Same flags, same artefacts (`configurations.json`, `logger.npy`,
 `epoch-XXX/generator.pth.tar`, per-epoch print), same schedule (Adam betas (0.5,0.999), StepLR
 stepped once per epoch before validation, checkpoint every 10 epochs); the per-batch
 `loss.item()` / sklearn R2 host syncs (train.py:113-114) are replaced by device accumulators read
-once per epoch.  Added flags: --dtype, --levels, --synthetic-steps, --pad-mode.
+once per epoch.  Added flags: --dtype, --levels, --grid, --synthetic-steps, --pad-mode, --f32-inputs.
+
+The data path is on the device too: by default every batch is written by ONE launch of the
+fuse / z-score / halo-pad kernel straight into the model's bf16 input slab (dataset.slab_batch);
+--f32-inputs materialises the reference's (B,T,C,Hp,Wp) f32 tensor first (dataset.device_batch).
 
     python nasa-niswan_amd/train.py --model LSTM-demo --in-channels 5 --sequence-length 12 \
         --input-size 100 154 --batch-size 8 --num-epochs 2 --snapshot-dir /tmp/snap
@@ -59,6 +63,11 @@ def get_arguments(argv=None, MODEL='LSTM-00', SPECIES='bcb', LEARNING_RATE=1.0E-
     parser.add_argument("--levels", type=int, default=1, help="vertical levels fused as channels (C = 3L+2)")
     parser.add_argument("--synthetic-steps", type=int, default=480, help="length of the synthetic record")
     parser.add_argument("--pad-mode", type=str, default="reference", choices=["reference", "reflect"])
+    parser.add_argument("--grid", nargs=2, type=int, default=(90, 144),
+                        help="un-padded lat x lon grid of the synthetic record; the loss crop is (input-size - grid)/2 "
+                             "(the reference hard-codes 90x144 and halo 5, train.py:102)")
+    parser.add_argument("--f32-inputs", action="store_true",
+                        help="materialise X as the reference's f32 (B,T,C,Hp,Wp) tensor instead of writing the input slab directly")
     args = parser.parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     if rank == 0:
@@ -96,13 +105,17 @@ def main(args):
     out_ch = args.levels
     generator = pkg.ConvLSTM(args.in_channels, list(args.hidden_channels), list(args.kernel_size), args.num_layers,
                              out_channels=out_ch, compute_dtype=args.dtype).to(dev)         # train.py:48
+    H, W = (int(v) for v in args.grid)
+    if args.input_size[0] < H or args.input_size[1] < W:
+        raise SystemExit(f"--input-size {tuple(args.input_size)} is smaller than --grid {(H, W)}: the model runs on the "
+                         "grid plus its halo (launcher.sh:24)")
+    halo = ((args.input_size[0] - H) // 2, (args.input_size[1] - W) // 2)                    # 5,5 in the reference (train.py:102)
     ds_kw = dict(species=args.species, padding=tuple(args.input_size), in_channels=args.in_channels,
                  sequence_length=args.sequence_length, levels=args.levels, n_steps=args.synthetic_steps,
-                 pad_mode=args.pad_mode, device=dev)
+                 grid=(H, W), pad_mode=args.pad_mode, device=dev)
     train_dataset = SyntheticE33OMA_CRNN('train', **ds_kw)                                   # train.py:63-65
     val_dataset = SyntheticE33OMA_CRNN('val', **ds_kw)
-    H, W = train_dataset.grid
-    halo = ((args.input_size[0] - H) // 2, (args.input_size[1] - W) // 2)                    # 5,5 in the reference (train.py:102)
+    get_batch = (lambda ds, idx: ds.device_batch(idx)) if args.f32_inputs else (lambda ds, idx: ds.slab_batch(idx))
 
     trainer = FusedTrainer(generator, lr=args.learning_rate, betas=tuple(args.betas), halo=halo)        # train.py:71
     optimizer = trainer.optimizer
@@ -111,25 +124,32 @@ def main(args):
     if args.use_checkpoint:
         load_checkpoint(f'{args.restore_from}/generator.pth.tar', generator, optimizer, args.learning_rate,
                         map_location=dev)                                                   # train.py:77-78
-    logger = {'MSELoss': [], 'r2_score': [], 'r2_score_val': []}
+    logger = {'MSELoss': [], 'r2_score': [], 'r2_score_val': [], 'first_step_loss': None, 'train_samples_per_s': []}
     for epoch in range(1, args.num_epochs + 1):                                              # train.py:82
         generator.train()
         trainer.reset_stats()
+        torch.cuda.synchronize()
+        t_epoch, n_epoch = time.time(), 0
         for idx in shard_indices(len(train_dataset), epoch, rank, world, args.batch_size):  # train.py:89
-            X, y = train_dataset.device_batch(idx)                                           # preproc on device
-            trainer.step(X, y)                                                               # train.py:96-110
-        loss_e, r2_e = trainer.epoch_stats()                                                 # one host read per epoch
+            X, y = get_batch(train_dataset, idx)                                             # preproc on device
+            loss = trainer.step(X, y)                                                        # train.py:96-110
+            n_epoch += len(idx)
+            if logger['first_step_loss'] is None:
+                logger['first_step_loss'] = float(loss)
+        loss_e, r2_e = trainer.epoch_stats()                                                 # one host read per epoch (syncs)
+        logger['train_samples_per_s'].append(world * n_epoch / max(time.time() - t_epoch, 1e-9))   # data path included
         logger['MSELoss'].append(loss_e)                                                     # (MSE+L1, as in train.py:116)
         logger['r2_score'].append(r2_e)
         scheduler.step()                                                                     # train.py:120
         generator.eval()
         trainer.reset_stats()
         for idx in shard_indices(len(val_dataset), 0, rank, world, 1, shuffle=False):        # utils.py:52-75, batch 1
-            trainer.evaluate(*val_dataset.device_batch(idx))
+            trainer.evaluate(*get_batch(val_dataset, idx))
         logger['r2_score_val'].append(trainer.epoch_stats()[1])
         if rank == 0:
             print(f"Epoch: {epoch}, Loss: {logger['MSELoss'][-1]:.5f}, R2T: {logger['r2_score'][-1]:.5f}, "
                   f"R2V: {logger['r2_score_val'][-1]:.5f}")                                  # train.py:124
+            print(f"  train loop incl. device preproc: {logger['train_samples_per_s'][-1]:.1f} samples/s")
             if epoch % 10 == 0:                                                              # train.py:126-136
                 d = os.path.join(args.snapshot_dir, f'epoch-{epoch:003d}')
                 os.makedirs(d, exist_ok=True)

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import NINT_LOSS_SCRATCH_FLOATS, check, ptr, stream_ptr
+from ._lib import NINT_LOSS_SCRATCH_FLOATS, NINT_LOSS_STATS, check, ptr, stream_ptr
 from .model import ConvLSTM
 from .optim import FlatParams, FusedAdam
 
@@ -36,7 +36,8 @@ class FusedTrainer:
         self.halo = tuple(halo)
         self.lib = _lib.load()
         self.scratch = torch.zeros(NINT_LOSS_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
-        self.stats = torch.zeros(5, dtype=torch.float64, device=dev)   # sum d^2, sum |d|, sum y, sum y^2, n
+        # [0..4] pooled: sum d^2, sum |d|, sum y, sum y^2, n; [5..7] per call: sum loss, sum r2_score, calls
+        self.stats = torch.zeros(NINT_LOSS_STATS, dtype=torch.float64, device=dev)
         self._dpred = None
         import torch.distributed as dist
         self.dist = dist
@@ -102,15 +103,20 @@ class FusedTrainer:
     def reset_stats(self):
         self.stats.zero_()
 
-    def epoch_stats(self):
-        """One device->host read per epoch.  Returns (mean loss, pooled R2) over everything accumulated
-        since reset_stats(); under DDP the five sums are all-reduced first."""
+    def epoch_stats(self, pooled: bool = False):
+        """One device->host read per epoch.  Returns what the reference logs over everything accumulated since
+        reset_stats(): (mean of the per-batch losses, mean of the per-batch sklearn ``r2_score``) -- train.py:113-117;
+        for the validation loop at batch size 1 that is the mean of per-sample R2 (utils.py:73-75).  Under DDP
+        the sums are all-reduced first, so the means run over every rank's batches.
+        ``pooled=True`` appends the pooled R2 over all elements seen (1 - sum d^2 / sum (y - mean y)^2)."""
         s = self.stats.clone()
         if self.world > 1:
             self.dist.all_reduce(s, op=self.dist.ReduceOp.SUM, group=self.pg)
-        s2, s1, sy, syy, n = (float(v) for v in s.cpu())
-        if n == 0:
-            return float("nan"), float("nan")
-        loss = s2 / n + s1 / n
-        ss_tot = syy - sy * sy / n
-        return loss, 1.0 - s2 / ss_tot if ss_tot > 0 else float("nan")
+        s2, s1, sy, syy, n, sl, sr2, calls = (float(v) for v in s.cpu())
+        if calls == 0:
+            return (float("nan"),) * (3 if pooled else 2)
+        out = (sl / calls, sr2 / calls)
+        if pooled:
+            ss_tot = syy - sy * sy / n
+            out += (1.0 - s2 / ss_tot if ss_tot > 0 else float("nan"),)
+        return out

@@ -52,11 +52,15 @@ def load_checkpoint(checkpoint_file, model, optimizer=None, lr=None, map_locatio
 
 def shard_indices(n: int, epoch: int, rank: int, world: int, batch_size: int, shuffle: bool = True, seed: int = 0):
     """Batch-sharded sampler: an epoch-seeded permutation (the reference's DataLoader(shuffle=True),
-    train.py:67) cut into global batches of world*batch_size; rank r takes slice r of each.  The
-    ragged tail (fewer than world*batch_size samples) is dropped so that every rank runs the same
-    number of steps.  Returns a list of index arrays, one per step."""
+    train.py:67) cut into global batches of world*batch_size; rank r takes slice r of each.  With one
+    rank the ragged tail batch is kept, as the reference's DataLoader (drop_last=False) keeps it; with
+    several ranks it is dropped so that every rank runs the same number of steps (the gradient
+    all-reduce is a collective).  Returns a list of index arrays, one per step."""
     rng = np.random.default_rng(seed + epoch)
     order = rng.permutation(n) if shuffle else np.arange(n)
     gb = world * batch_size
     steps = n // gb
-    return [order[s * gb + rank * batch_size: s * gb + (rank + 1) * batch_size] for s in range(steps)]
+    out = [order[s * gb + rank * batch_size: s * gb + (rank + 1) * batch_size] for s in range(steps)]
+    if world == 1 and n % gb:
+        out.append(order[steps * gb:])
+    return out

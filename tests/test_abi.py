@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in nint.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.nint_version() == 103
+    assert lib.nint_version() == 104
     assert lib.nint_kc(0) == 16 and lib.nint_kc(1) == 32
     assert lib.nint_error_string(-2).decode().startswith("nint:")
 
@@ -119,3 +119,13 @@ def test_modules_pickle_and_deepcopy_without_their_engines():
     assert twin._engines == {} and torch.equal(twin.conv.weight, net.conv.weight)
     again = pickle.loads(pickle.dumps(net))
     assert again._engines == {} and list(again.state_dict()) == list(net.state_dict())
+
+
+def test_untrainable_kernel_sizes_are_known_before_any_backward():
+    """The reference accepts any odd k (model.py:204); the weight-gradient kernel is instantiated for 1, 3, 5.
+    The engine learns that from the library at construction (pure host arithmetic, no GPU) and refuses a TRAINING
+    workspace with a message that names the layer, instead of a generic shape error in the first backward()."""
+    from nasa_niswan_amd.engine import LayerCfg, SeqEngine
+    assert SeqEngine.untrainable_layers([LayerCfg(5, 64, 5), LayerCfg(64, 32, 3), LayerCfg(32, 16, 1)], "bf16") == []
+    bad = SeqEngine.untrainable_layers([LayerCfg(5, 16, 3), LayerCfg(16, 8, 7)], "f32")
+    assert len(bad) == 1 and "layer 1" in bad[0] and "k=7" in bad[0]

@@ -142,3 +142,20 @@ def test_heavy_tail_inputs(pkg, dtype):
         assert torch.isfinite(p.grad).all(), k
         res["grad." + k] = (p.grad.cpu(), leaf[k].grad)
     check(res, dtype)
+
+
+def test_k7_forward_works_and_training_is_refused_early(pkg):
+    """The reference accepts any odd kernel size (padding k//2, model.py:204).  The gate kernel is generic in k; the
+    weight-gradient kernel is instantiated for k = 1, 3, 5 -- so a k=7 model runs forward / inference and is refused
+    a TRAINING workspace with a NintError naming the layer (not a shape error out of the first backward())."""
+    from oracle import convlstm_oracle as O
+    params = O.synth_params(3, [8], [7], 1, seed=7)
+    rng = np.random.default_rng(7)
+    X = torch.from_numpy(rng.standard_normal((2, 2, 3, 12, 20)).astype(np.float32))
+    net = pkg.ConvLSTM(3, [8], [7], 1).cuda()
+    net.load_state_dict(params)
+    with torch.no_grad():
+        pred = net(X.cuda()).cpu()
+    np.testing.assert_allclose(pred.numpy(), O.convlstm_forward(X, params).numpy(), rtol=1e-4, atol=1e-5)
+    with pytest.raises(pkg.NintError, match="layer 0.*k=7"):
+        net(X.cuda())

@@ -48,6 +48,53 @@ def test_fused_trainer_matches_reference_fit_loop_cfg0(pkg):
     assert abs(loss_e - np.mean([float(g[f"loss{s}"]) for s in (1, 2, 3)])) < 1e-5 and r2_e < 0.5
 
 
+def test_epoch_stats_are_the_reference_per_batch_means(pkg):
+    """f-1: the logged numbers are the reference's statistics -- the mean over batches of loss.item() and of
+    sklearn r2_score(y, pred) (train.py:113-117), and for validation at batch size 1 the mean of per-sample R2
+    (utils.py:73-75) -- not a pooled R2.  Checked (1) on the cfg0 goldens along three optimiser steps and (2) on a
+    synthetic 8-sample epoch cut into ragged batches 3+3+2 and into 8 batches of 1, tolerance 1e-6."""
+    from nasa_niswan_amd.trainer import FusedTrainer
+    from oracle import convlstm_oracle as O
+    g = np.load(os.path.join(GOLD, "cfg0_train.npz"))
+    params = {k[len("params0."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("params0.")}
+    net = pkg.ConvLSTM(4, [8], [3], 1).cuda()
+    net.load_state_dict(params)
+    lr, betas = float(g["lr"]), tuple(float(b) for b in g["betas"])
+    tr = FusedTrainer(net, lr=lr, betas=betas, halo=(0, 0))
+    X, y = torch.from_numpy(g["X"]), torch.from_numpy(g["y"])
+    # the golden prediction of step 1 pins the oracle's R2 of that batch
+    r2_gold = O.r2_score_np(g["y"], g["pred_full"][:, 0])
+    p, st, r2s, losses = params, None, [], []
+    for step in (1, 2, 3):
+        tr.step(X.cuda(), y.cuda())
+        p, st, oloss, opred, _ = O.train_step(p, st, X, y, lr=lr, betas=betas, halo=(0, 0))
+        r2s.append(O.r2_score_np(y.numpy(), opred.numpy()))
+        losses.append(oloss)
+    assert abs(r2s[0] - r2_gold) < 1e-7
+    loss_e, r2_e, r2_pool = tr.epoch_stats(pooled=True)
+    print(f"  cfg0: mean per-batch R2 {r2_e:.7f} (oracle {np.mean(r2s):.7f}), pooled {r2_pool:.7f}; loss {loss_e:.7f}")
+    assert abs(r2_e - np.mean(r2s)) < 1e-6 and abs(loss_e - np.mean(losses)) < 2e-6
+
+    params = O.synth_params(5, [8, 8], [3, 3], 2, seed=12)
+    X, y = O.synth_batch(8, 3, 5, 20, 28, (10, 18), seed=12)
+    y = y * torch.linspace(0.5, 3.0, 8).view(8, 1, 1) + torch.linspace(-1, 1, 8).view(8, 1, 1)   # per-sample spread: pooled != mean
+    net = pkg.ConvLSTM(5, [8, 8], [3, 3], 2).cuda()
+    net.load_state_dict(params)
+    tr = FusedTrainer(net, lr=1e-3, halo=(5, 5))
+    po = O.crop_pred(O.convlstm_forward(X, params), (5, 5), (10, 18))[:, 0]
+    for cuts in ([(0, 3), (3, 6), (6, 8)], [(i, i + 1) for i in range(8)]):
+        tr.reset_stats()
+        for a, b in cuts:
+            tr.evaluate(X[a:b].cuda(), y[a:b].cuda())
+        loss_e, r2_e, r2_pool = tr.epoch_stats(pooled=True)
+        want_r2 = np.mean([O.r2_score_np(y[a:b].numpy(), po[a:b].numpy()) for a, b in cuts])
+        want_loss = np.mean([float(O.loss_mse_l1(y[a:b], po[a:b])) for a, b in cuts])
+        want_pool = O.r2_score_np(y.numpy(), po.numpy())
+        print(f"  {len(cuts)} batches: R2 {r2_e:.7f} (oracle {want_r2:.7f}), pooled {r2_pool:.7f} (oracle {want_pool:.7f})")
+        assert abs(r2_e - want_r2) < 1e-6 and abs(loss_e - want_loss) < 2e-6 * abs(want_loss) + 1e-7
+        assert abs(r2_pool - want_pool) < 1e-6 and abs(want_pool - want_r2) > 1e-3      # the two statistics do differ here
+
+
 def test_reference_style_autograd_loop_equals_fused_trainer(pkg):
     from nasa_niswan_amd.optim import FlatParams, FusedAdam
     from nasa_niswan_amd.trainer import FusedTrainer
@@ -90,6 +137,52 @@ def test_dataset_device_batch_matches_oracle_preproc(pkg):
         assert torch.equal(Xi, X[1]) and yi.shape == ((90, 144) if levels == 1 else (levels, 90, 144))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_slab_batch_is_bit_identical_to_preproc_then_pack(pkg, dtype):
+    """a-6 straight into the slab: `nint_preproc_fuse_pad_slab` (one launch per batch, no f32 intermediate) must
+    write exactly the bytes that the oracle's preproc followed by the pack kernel's rounding produces: compared
+    (1) byte for byte with device_batch -> nint_pack_btchw on the same windows, whose f32 values are themselves
+    checked against preproc_oracle above, and (2) directly against preproc_oracle rounded to the slab type."""
+    import ctypes as C
+    from nasa_niswan_amd import _lib
+    from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
+    from nasa_niswan_amd.engine import LayerCfg, SeqEngine
+    from oracle import preproc_oracle as PO
+    for levels, mode, idx in ((1, "reference", [3, 0, 9]), (20, "reflect", [1, 5])):
+        Cin = 3 * levels + 2
+        ds = SyntheticE33OMA_CRNN("train", padding=(100, 154), in_channels=Cin, sequence_length=3, levels=levels,
+                                  n_steps=24, pad_mode=mode, device="cuda")
+        eng = SeqEngine([LayerCfg(Cin, 16, 3)], dtype, "cuda")
+        B = len(idx)
+        ws_a = eng.acquire(B, 3, 100, 154, False, False)
+        ws_b = eng.acquire(B, 3, 100, 154, False, False)
+        assert ws_a is not ws_b
+        sb, y1 = ds.slab_batch(idx)
+        sb.fill_slab(eng, ws_a)
+        X, y2 = ds.device_batch(idx)
+        _lib.check(_lib.load().nint_pack_btchw(_lib.ptr(X), _lib.ptr(ws_b.xs), B, 3, Cin, ws_b.Cxp0, C.byref(ws_b.g), eng.dt,
+                                               _lib.stream_ptr()), "pack")
+        torch.cuda.synchronize()
+        assert torch.equal(ws_a.xs, ws_b.xs) and torch.equal(y1, y2), (levels, mode)
+        # directly against the oracle: image t*B+b, interior [P, P+100) x [P, P+154), channels-last
+        g, Cp = ws_a.g, ws_a.Cxp0
+        et = torch.float32 if dtype == "f32" else torch.bfloat16
+        slab = ws_a.xs.view(et).view(3 * B, g.Hh, g.Wh, Cp)[:, g.P:g.P + 100, g.P:g.P + 154].float().cpu()
+        assert float(ws_a.xs.view(et).view(3 * B, g.Hh, g.Wh, Cp)[:, :, :, Cin:].abs().max()) == 0.0      # channel padding zero
+        for b, i in enumerate(idx):
+            fields, _ = ds.window(i)
+            args = [f if (levels > 1 or f.ndim == 3) else f[:, 0] for f in fields]
+            ref = torch.from_numpy(PO.preproc_sample(*args, ds.X_mean, ds.X_std, (100, 154), mode))   # (T,C,Hp,Wp)
+            want = ref.to(et).float().permute(0, 2, 3, 1)
+            got = slab[b::B][:, :, :, :Cin]
+            if dtype == "f32":
+                np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+            else:   # the f32 value may differ from numpy's in the last bit before rounding: <= 1 bf16 ulp, and rarely
+                d = (got - want).abs()
+                assert float((d > 0).float().mean()) < 1e-3 and float((d / (want.abs() + 1e-6)).max()) <= 2 ** -7
+        eng.release(ws_a); eng.release(ws_b)
+
+
 def test_train_py_end_to_end(pkg, tmp_path, monkeypatch):
     from nasa_niswan_amd import train as T
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -114,6 +207,37 @@ def test_train_py_end_to_end(pkg, tmp_path, monkeypatch):
     logger2 = T.main(T.get_arguments(argv[:-4] + ["--synthetic-steps", "36", "--dtype", "f32", "--use-checkpoint",
                                                    "--restore-from", str(snap / "epoch-010"), "--num-epochs", "1"]))
     assert logger2["MSELoss"][0] < logger["MSELoss"][0]
+
+
+def test_train_py_runs_baseline_config0(pkg, tmp_path, monkeypatch):
+    """BASELINE.json configs[0] through the fit-loop entry point itself: 1-layer ConvLSTM, 32x32 synthetic grid,
+    4 in-channels, seq_len 4, batch 2 (on the MI355X: this build has no CPU leg).  The crop is derived from
+    --input-size vs --grid (halo 0 here; the reference hard-codes 5, train.py:102).  The first step's loss must
+    equal the oracle's fit-loop step on the same first batch, and both data paths (slab-direct / f32 tensor) agree."""
+    from nasa_niswan_amd import train as T
+    from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
+    from nasa_niswan_amd.utils import shard_indices
+    from oracle import convlstm_oracle as O
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    argv = ["--model", "LSTM-cfg0", "--in-channels", "4", "--hidden-channels", "8", "--kernel-size", "3", "--num-layers", "1",
+            "--sequence-length", "4", "--input-size", "32", "32", "--grid", "32", "32", "--batch-size", "2", "--num-epochs", "2",
+            "--learning-rate", "1e-4", "--synthetic-steps", "24", "--dtype", "f32", "--snapshot-dir", str(tmp_path / "s")]
+    logger = T.main(T.get_arguments(argv))
+    assert len(logger["MSELoss"]) == 2 and np.isfinite(logger["MSELoss"]).all() and np.isfinite(logger["r2_score_val"]).all()
+    ds = SyntheticE33OMA_CRNN("train", padding=(32, 32), in_channels=4, sequence_length=4, n_steps=24, grid=(32, 32), device="cuda")
+    assert ds.generic and len(ds) == 17
+    idx = shard_indices(len(ds), 1, 0, 1, 2)
+    assert len(idx) == 9 and len(idx[-1]) == 1                       # ragged tail batch kept (DataLoader drop_last=False)
+    X, y = ds.device_batch(idx[0])
+    params = O.init_params(4, [8], [3], 1, seed=0)                    # seed(0) then ConvLSTM(...): train.py:32,48
+    _, _, oloss, _, _ = O.train_step(params, None, X.cpu(), y.cpu(), lr=1e-4, halo=(0, 0))
+    print(f"  first-step loss {logger['first_step_loss']:.7f}, oracle {oloss:.7f}")
+    assert abs(logger["first_step_loss"] - oloss) <= 2e-6 * abs(oloss)
+    logger2 = T.main(T.get_arguments(argv + ["--f32-inputs"]))
+    assert logger2["first_step_loss"] == logger["first_step_loss"] and logger2["MSELoss"] == logger["MSELoss"]
+    with pytest.raises(SystemExit):                                   # a grid larger than the model input is refused
+        T.main(T.get_arguments(argv[:-2] + ["--snapshot-dir", str(tmp_path / "t"), "--grid", "40", "40"]))
 
 
 def test_bench_under_torchrun_with_rccl_group(pkg):

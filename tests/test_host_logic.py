@@ -41,8 +41,11 @@ def test_shard_indices_partitions_each_global_batch():
     assert len(seen) == len(set(seen.tolist())) == (n // 8) * 8          # disjoint, ragged tail dropped
     # world=1 sees the same global batches in the same order
     one = shard_indices(n, 3, 0, 1, bs * world)
-    for s in range(len(one)):
+    for s in range(len(per_rank[0])):
         np.testing.assert_array_equal(one[s], np.concatenate([per_rank[0][s], per_rank[1][s]]))
+    # a single rank keeps the ragged tail batch, as the reference's DataLoader(drop_last=False) does (train.py:67)
+    assert len(one) == n // 8 + 1 and len(one[-1]) == n % 8
+    assert sorted(np.concatenate(one).tolist()) == list(range(n))
     assert not np.array_equal(np.concatenate(shard_indices(n, 4, 0, 1, 8)), np.concatenate(one))   # reshuffled per epoch
     np.testing.assert_array_equal(np.concatenate(shard_indices(10, 0, 0, 1, 1, shuffle=False)), np.arange(10))
 
@@ -63,8 +66,12 @@ def test_synthetic_dataset_windows_and_splits():
     assert tr.X_mean.shape == (5,) and va.first[0] == 70
     lv = SyntheticE33OMA_CRNN("train", padding=(100, 154), in_channels=14, sequence_length=4, levels=4, n_steps=40, device="cpu")
     assert lv.X_mean.shape == (14,)
-    with pytest.raises(AssertionError):
-        SyntheticE33OMA_CRNN("train", in_channels=8, sequence_length=4, n_steps=40, device="cpu")   # static attrs out of scope
+    # a channel count that is not 3L+2 (BASELINE configs[0]: 4 channels on 32x32) synthesises generic fields;
+    # the reference's static-attribute channels (dataset.py:100-122) stay out of scope
+    gen = SyntheticE33OMA_CRNN("train", padding=(32, 32), in_channels=4, sequence_length=4, n_steps=24, grid=(32, 32), device="cpu")
+    assert gen.generic and gen.X_mean.shape == (4,) and len(gen) == 17
+    (f,), y = gen.window(2)
+    assert f.shape == (4, 4, 32, 32) and y.shape == (1, 32, 32)
 
 
 def _tiny():

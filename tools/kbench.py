@@ -121,7 +121,17 @@ def main():
         run(f"wgrad{l}", wg, flw)
     xs_pack = lambda: lib.nint_pack_btchw(C.c_void_p(X.data_ptr()), C.c_void_p(ws.xs.data_ptr()), B, T, args.C, ws.Cxp0, g, eng.dt, st)
     run("pack", xs_pack, None, X.numel() * 4 + B * T * comp_px * ws.Cxp0 * es)
-    tot = sum(ms * (T if not n.startswith(("wgrad", "pack")) else 1) for n, ms in rows)
+    if args.C % 3 == 2 and (not only or only & {"preproc_slab", "preproc_nchw"}):
+        # a-6: fuse + z-score + halo pad of a whole batch in one launch, from a record resident in HBM
+        from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
+        ds = SyntheticE33OMA_CRNN("train", padding=(H, W), in_channels=args.C, sequence_length=T, levels=(args.C - 2) // 3,
+                                  n_steps=T + 2 * B + 4, grid=(H - 10, W - 10), device="cuda")
+        idx = list(range(0, 2 * B, 2))
+        sb, _ = ds.slab_batch(idx)
+        alg = B * T * args.C * H * W
+        run("preproc_slab", lambda: sb.fill_slab(eng, ws), None, alg * (4 + es))     # 4 B in + ET out per element
+        run("preproc_nchw", lambda: ds.device_batch(idx), None, alg * 8)
+    tot = sum(ms * (T if not n.startswith(("wgrad", "pack", "preproc")) else 1) for n, ms in rows if n != "preproc_nchw")
     print(f"sum over a step (T x per-step kernels + wgrad + pack): {tot:.2f} ms")
 
 
