@@ -61,6 +61,29 @@ def time_kernel(fn, iters, stream):
     return ev0.elapsed_time(ev1) / iters
 
 
+def host_cpu():
+    """(model name, physical core count) of this box from /proc/cpuinfo"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or os.cpu_count() or 1)
+
+
 def cpu_baseline(name, steps=3):
     """The CPU oracle (plain PyTorch CPU ops = the ATen path the reference takes on CPU) timed on
     this box's host cores on a bounded sample of the same workload: B=2, f32, 1 warm-up + `steps`
@@ -68,7 +91,10 @@ def cpu_baseline(name, steps=3):
     from oracle import convlstm_oracle as O      # checker / baseline only -- never on the product path
     C, hidden, ks, out, T, Hp, Wp, halo, grid = WORKLOADS[name]
     B = 2
-    threads = torch.get_num_threads()
+    model, phys = host_cpu()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(phys, avail))           # one thread per physical core this process may use
+    torch.set_num_threads(threads)
     params = O.synth_params(C, hidden, ks, len(hidden), out_channels=out, seed=0)
     import numpy as np
     rng = np.random.default_rng(0)
@@ -81,7 +107,25 @@ def cpu_baseline(name, steps=3):
         params, state, *_ = O.train_step(params, state, X, y, lr=1e-3, halo=halo)
     dt = time.perf_counter() - t0
     return {"value": round(B * steps / dt, 4), "unit": "samples/s", "cores": threads, "kind": "port",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus_available": avail,
             "sample": f"{name} at B={B}, f32, {steps} timed train steps after 1 warm-up ({dt:.1f} s of CPU work)"}
+
+
+def executed_flops_per_sample(C, hidden, ks, out, T, Hp, Wp):
+    """FLOPs a training step really has to execute (algorithmic channel counts, no padding): the zero initial state
+    removes the h half of K at t = 0 from the forward, its dgrad and its weight gradient (model.py:259-262), and the
+    input gradient of layer 0 is never needed (train.py:109 only differentiates the parameters)."""
+    px = 2 * Hp * Wp
+    fwd = dgrad = wgrad = 0
+    cin = C
+    for l, (ch, k) in enumerate(zip(hidden, ks)):
+        per = px * k * k * 4 * ch
+        fwd += per * (T * cin + (T - 1) * ch)
+        wgrad += per * (T * cin + (T - 1) * ch)
+        dgrad += per * ((T * cin if l > 0 else 0) + (T - 1) * ch)
+        cin = ch
+    head = px * hidden[-1] * out
+    return fwd + dgrad + wgrad + 3 * head
 
 
 def main():
@@ -143,8 +187,10 @@ def main():
         elapsed = float(t)
     final_loss = float(loss)
 
-    # ---- roofline of the dominant kernel: the layer-0 fused gate kernel (conv_igemm, LSTM epilogue)
-    roof = None
+    # ---- rooflines of the four kernels that are ~3/4 of the step, each timed live with HIP events on the launch
+    # stream (back-to-back launches on the bench's own slabs, i.e. real data): layer-0 gate kernel (forward), layer-0
+    # weight gradient, layer-0 dgrad, layer-0 LSTM pointwise backward.  `roofline` = the dominant one.
+    roof, roof_all = None, None
     if rank == 0:
         import ctypes as Ct
         eng = model._engine(dev)
@@ -152,43 +198,81 @@ def main():
         lib = pkg.load_library()
         ly, g = eng.layers[0], ws.g
         st = torch.cuda.current_stream()
-        # t = 1 step of layer 0: x slab image B.., h_prev = slab 1, c_prev = slot 1 -> writes slot 2
+        sp = Ct.c_void_p(st.cuda_stream)
         kc, es = eng.kc, eng.es
         halo_px, comp_px = g.Hh * g.Wh, Hp * Wp
-        xs = ws.xs.data_ptr() + 1 * B * halo_px * ly.Cxp * es
-        hs = B * halo_px * ly.Chp * es
-        cs = B * comp_px * ly.Chp * 4
-        gs = B * comp_px * 4 * ly.Ch16 * es
-
-        def one():
-            rc = lib.nint_cell_fwd(Ct.byref(ly), Ct.byref(g), eng.dt, B, Ct.c_void_p(xs), Ct.c_void_p(ws.h[0].data_ptr() + hs),
-                                   Ct.c_void_p(ws.c[0].data_ptr() + cs), Ct.c_void_p(ws.h[0].data_ptr() + 2 * hs),
-                                   Ct.c_void_p(ws.c[0].data_ptr() + 2 * cs), Ct.c_void_p(ws.gates[0].data_ptr() + gs),
-                                   Ct.c_void_p(st.cuda_stream))
-            assert rc == 0
-        ms = time_kernel(one, 50, st)
-        eng.release(ws)
         k0, ch0 = ks[0], hidden[0]
-        flops = 2.0 * B * Hp * Wp * k0 * k0 * (C + ch0) * 4 * ch0          # algorithmic, per launch
-        achieved = flops / (ms * 1e-3) / 1e12
+        hs, cs = B * halo_px * ly.Chp * es, B * comp_px * ly.Chp * 4
+        gs, dgs = B * comp_px * 4 * ly.Ch16 * es, B * halo_px * 4 * ly.Ch16 * es
+        xs1 = ws.xs.data_ptr() + 1 * B * halo_px * ly.Cxp * es
+        vp = Ct.c_void_p
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        # HBM bytes per launch of this kernel from the committed PMC pass (not collected live: PMC needs
-        # rocprofv3 around the process); only quoted for the exact configuration it was measured on
-        traffic = None
+        traffic = {}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = f"{args.workload}/{args.dtype}/B{B}/conv_igemm_fwd_layer0"
-            traffic = tj.get(key, {}).get("bytes_per_launch")
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         except (OSError, ValueError):
             pass
-        roof = {"kernel": "conv_igemm_kernel<LSTM epilogue> layer 0 (B images, one time step)", "bound": "mfma",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
+
+        def entry(key, kernel, bound, work, ms, note=None):
+            """work = algorithmic FLOPs (mfma) or bytes (hbm) per launch"""
+            if bound == "mfma":
+                ach, pk, unit = work / (ms * 1e-3) / 1e12, peak, "TFLOP/s"
+            else:
+                ach, pk, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            # HBM bytes per launch from the committed PMC pass (PMC needs rocprofv3 around the process, so it is
+            # not collected live); only quoted for the exact configuration it was measured on
+            tr = traffic.get(f"{args.workload}/{args.dtype}/B{B}/{key}", {}).get("bytes_per_launch")
+            e = {"kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": pk, "unit": unit,
+                 "frac": round(ach / pk, 4), "traffic": tr, "ms_per_launch": round(ms, 4),
+                 ("flops_per_launch" if bound == "mfma" else "bytes_per_launch"): work}
+            if note:
+                e["note"] = note
+            return e
+
+        # t = 1 step of layer 0: x slab image B.., h_prev = slab 1, c_prev = slot 1 -> writes slot 2
+        def k_fwd():
+            assert lib.nint_cell_fwd(Ct.byref(ly), Ct.byref(g), eng.dt, B, vp(xs1), vp(ws.h[0].data_ptr() + hs),
+                                     vp(ws.c[0].data_ptr() + cs), vp(ws.h[0].data_ptr() + 2 * hs), vp(ws.c[0].data_ptr() + 2 * cs),
+                                     vp(ws.gates[0].data_ptr() + gs), sp) == 0
+
+        def k_dgrad():      # as in the step: h columns only (no input gradient for layer 0)
+            assert lib.nint_conv_dgrad(Ct.byref(ly), Ct.byref(g), eng.dt, B, vp(ws.dG[0].data_ptr() + dgs), None,
+                                       vp(ws.dh[0].data_ptr()), sp) == 0
+
+        def k_pw():
+            assert lib.nint_cell_bwd_pointwise(Ct.byref(ly), Ct.byref(g), eng.dt, B, vp(ws.gates[0].data_ptr() + gs),
+                                               vp(ws.c[0].data_ptr() + cs), vp(ws.c[0].data_ptr() + 2 * cs), vp(ws.dh[0].data_ptr()),
+                                               vp(ws.dc[0].data_ptr()), vp(ws.dG[0].data_ptr() + dgs), vp(ws.dbp[0].data_ptr()), sp) == 0
+
+        dW0, db0 = trainer._dW[0], trainer._db[0]
+
+        def k_wgrad():      # both sources (x and h) over all T time steps + the split-K fold + the bias-gradient fold
+            assert lib.nint_conv_wgrad(Ct.byref(ly), Ct.byref(g), eng.dt, T * B, vp(ws.dG[0].data_ptr()), vp(ws.xs.data_ptr()),
+                                       vp(ws.h[0].data_ptr()), vp(dW0.data_ptr()), vp(db0.data_ptr()), vp(eng.wg_partial.data_ptr()),
+                                       eng.wg_partial.numel() * 4, eng.n_cu, vp(ws.dbp[0].data_ptr()), T * 1024, sp) == 0
+
+        f_gate = 2.0 * B * Hp * Wp * k0 * k0 * (C + ch0) * 4 * ch0           # algorithmic, per launch
+        f_dgrad = 2.0 * B * Hp * Wp * k0 * k0 * 4 * ch0 * ch0
+        f_wgrad = 2.0 * T * B * Hp * Wp * k0 * k0 * (C + ch0) * 4 * ch0
+        b_pw = float(B * comp_px * ch0 * (9 * es + 16))     # gates + dG (4 ET each) + dh (ET); c_prev, c_new, dc in, dc out (f32)
+        roof = entry("conv_igemm_fwd_layer0", "conv_igemm_kernel<LSTM epilogue> layer 0 (B images, one time step)", "mfma",
+                     f_gate, time_kernel(k_fwd, 50, st))
+        roof_all = [
+            dict(roof, launches_per_step=T),
+            dict(entry("wgrad_layer0", "wgrad_kernel layer 0: x part + h part over all T steps, incl. split-K and bias folds",
+                       "mfma", f_wgrad, time_kernel(k_wgrad, 10, st)), launches_per_step=1),
+            dict(entry("conv_igemm_dgrad_layer0", "conv_igemm_kernel<DGRAD epilogue> layer 0 (h columns; B images, one time step)",
+                       "mfma", f_dgrad, time_kernel(k_dgrad, 50, st)), launches_per_step=T - 1),
+            dict(entry("lstm_bwd_pointwise_layer0", "lstm_bwd_pointwise_kernel layer 0 (B images, one time step)", "hbm",
+                       b_pw, time_kernel(k_pw, 50, st)), launches_per_step=T),
+        ]
+        eng.release(ws)
 
     samples = world * B * args.steps
     value = samples / elapsed
     if rank == 0:
         f_train = 3 * fwd_flops_per_sample(C, hidden, ks, out, T, Hp, Wp)
+        f_exec = executed_flops_per_sample(C, hidden, ks, out, T, Hp, Wp)
         line = {
             "metric": "training samples/sec (90x144x20 grid, seq_len=12)",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,10 +281,15 @@ def main():
             "config": {"workload": args.workload, "in_channels": C, "hidden": list(hidden), "kernels": list(ks),
                        "out_channels": out, "seq_len": T, "padded_grid": [Hp, Wp], "grid": list(grid),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "whole_step_tflops": round(value * f_train / 1e12, 2),
-            "whole_step_mfma_frac": round(value * f_train / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4),
+            # whole step priced two ways: the survey's nominal 3 x F_fwd, and the FLOPs the step really executes
+            # (zero-state h parts and the layer-0 input gradient are legitimately skipped)
+            "whole_step_nominal_tflops": round(value * f_train / 1e12, 2),
+            "whole_step_nominal_mfma_frac": round(value * f_train / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4),
+            "whole_step_executed_tflops": round(value * f_exec / 1e12, 2),
+            "whole_step_executed_mfma_frac": round(value * f_exec / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4),
             "final_loss": round(final_loss, 5),
             "roofline": roof,
+            "roofline_kernels": roof_all,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.workload)

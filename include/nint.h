@@ -13,7 +13,8 @@
  *   - every entry returns 0 on success, a negative NINT_E_* code for bad arguments or a
  *     positive hipError_t value; nothing throws or aborts.
  *   - the caller owns all memory (the Python side allocates through torch's caching
- *     allocator); the library keeps no state between calls.
+ *     allocator); the library keeps no state between calls, reads no environment variables and owns
+ *     no streams or events: every launch goes to the caller's stream.
  *
  * Internal data layout ("slabs"), chosen for gfx950 rather than inherited from NCHW:
  *   halo slab     ET [N][Hh][Wh][Cp]   channels-last, ET = float or bf16, physical zero halo P
@@ -59,7 +60,8 @@ typedef struct nint_layer {
   int32_t Cx, Cxp;        /* input channels / padded to KC */
   int32_t Ch, Ch16, Chp;  /* hidden channels / padded to 16 / padded to KC */
   int32_t k;              /* odd kernel size, padding k/2 (model.py:204) */
-  int32_t reserved0, reserved1;
+  int32_t tile_rows;      /* rows of the gate / dgrad kernels' pixel tile: 0 = chosen per launch shape, or 4 / 8 */
+  int32_t reserved1;
   const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */
   const void* Wd;         /* dgrad weights (transposed + flipped), ET */
   const float* bias_p;    /* bias permuted to gate-stash column order [4*Ch16] */
@@ -157,17 +159,6 @@ int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                     const float* db_partial, int db_rows, void* stream);
 /* db_partial/db_rows: the rows written by the fused pointwise-backward launches of all time steps
  * (db = their column sum); NULL -> db is computed by a column-sum pass over dG instead. */
-
-/* The same reduction in time chunks (the sequence driver overlaps early chunks with the rest of
- * BPTT): every chunk writes its slabs with the layout of the plan for N_plan images; finalize folds
- * `nchunks` chunks spaced chunk_stride_floats apart. */
-int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
-                            const void* dG, const void* x_slab, const void* h_slab, float* partial,
-                            size_t partial_bytes, int n_cu, void* stream);
-int nint_conv_wgrad_finalize(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int nchunks,
-                             size_t chunk_stride_floats, int N_total, const void* dG, float* dW, float* db,
-                             float* partial, int n_cu, const float* db_partial, int db_rows, void* stream);
-#define NINT_WGRAD_CHUNKS 4   /* time chunks nint_seq_bwd uses when the workspace allows */
 
 /* ---- whole-sequence drivers (model.py:253-274 and its BPTT), all launches from C++ ---------- */
 int nint_seq_fwd(const nint_seq* s /*host*/, void* stream);

@@ -15,7 +15,6 @@ NINT_MAX_LAYERS = 8
 NINT_LOSS_SCRATCH_FLOATS = 2050
 NINT_LOSS_STATS = 8
 NINT_DB_ROWS = 1024
-NINT_WGRAD_CHUNKS = 4
 
 vp = C.c_void_p
 
@@ -26,7 +25,7 @@ class NintGeom(C.Structure):
 
 class NintLayer(C.Structure):
     _fields_ = [("Cx", C.c_int32), ("Cxp", C.c_int32), ("Ch", C.c_int32), ("Ch16", C.c_int32), ("Chp", C.c_int32),
-                ("k", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+                ("k", C.c_int32), ("tile_rows", C.c_int32), ("reserved1", C.c_int32),
                 ("Wf", vp), ("Wd", vp), ("bias_p", vp)]
 
 
@@ -61,8 +60,6 @@ SIGNATURES = {
     "nint_conv_dgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp]),
     "nint_wgrad_workspace_bytes": (_SZ, [_PL, _I, _I]),
     "nint_conv_wgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, _SZ, _I, vp, _I, vp]),
-    "nint_conv_wgrad_partial": (_I, [_PL, _PG, _I, _I, _I, _I, vp, vp, vp, vp, _SZ, _I, vp]),
-    "nint_conv_wgrad_finalize": (_I, [_PL, _PG, _I, _I, _I, _SZ, _I, vp, vp, vp, vp, _I, vp, _I, vp]),
     "nint_seq_fwd": (_I, [_PS, vp]),
     "nint_seq_bwd": (_I, [_PS, vp]),
     "nint_head_fwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, _PG, _I, vp]),

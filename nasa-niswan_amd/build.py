@@ -26,7 +26,13 @@ def _newer(a, bs):
     return os.path.exists(a) and all(os.path.getmtime(a) >= os.path.getmtime(b) for b in bs)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, exp: bool = False) -> str:
+    """exp=True: the EXPERIMENT build (-DNINT_EXPERIMENT: extra tile configurations selectable through
+    nint_layer.reserved1 for tools/kbench.py) into libnint_hip_exp.so; never loaded by the package itself."""
+    global OBJ, LIB, FLAGS
+    if exp:
+        OBJ, LIB = os.path.join(HERE, "build_exp"), os.path.join(HERE, "libnint_hip_exp.so")
+        FLAGS = FLAGS + ["-DNINT_EXPERIMENT"]
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "nint_common.h"), os.path.join(ROOT, "include", "nint.h")]
     objs, jobs = [], []
@@ -53,4 +59,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, exp="--exp" in sys.argv))

@@ -21,7 +21,6 @@
 //     lane owns 4 consecutive channels of one pixel -> 16-byte / 8-byte vector epilogue; the
 //     i,f,g,o tiles of one hidden channel sit in the same lane (column order
 //     n' = (cblock*4+gate)*16+col), so the LSTM epilogue needs no cross-lane traffic.
-#include <stdlib.h>
 #include "nint_common.h"
 
 enum { EPI_LSTM = 0, EPI_DGRAD = 1 };
@@ -477,17 +476,21 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
 template <int DT, int EPI>
 static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   if (ntiles <= 0) return NINT_OK;
-  // short-K launches (narrow layers) take 4-row tiles; NINT_MT=4|8 in the environment overrides
-  static const int mt_env = [] { const char* e = getenv("NINT_MT"); return e ? atoi(e) : 0; }();
-  const bool mt4 = mt_env ? mt_env == 4 : ((a.nchunk0 + a.nchunk1) * a.taps <= 48 || ntiles <= 4);
+  // short-K launches (narrow layers) take 4-row tiles; nint_layer.tile_rows = 4 | 8 overrides (tests run both
+  // heights on every shape)
+  const bool mt4 = a.tile_rows ? a.tile_rows == 4 : ((a.nchunk0 + a.nchunk1) * a.taps <= 48 || ntiles <= 4);
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;
-    if (mt_env == 6 && cbs % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 4, 6>(a, N, cbs / 4, st);
     if (cbs % 4 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, cbs / 4, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, cbs / 4, st);
     if (cbs % 2 == 0) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st);
     return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st);
   } else {
+#ifdef NINT_EXPERIMENT
+    if (a.dbg == 1 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 8>(a, N, ntiles / 4, st);
+    if (a.dbg == 2 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 4>(a, N, ntiles / 4, st);
+    if (a.dbg == 3 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 1, 8>(a, N, ntiles / 4, st);
+#endif
     // (WN, NTW) with WN*NTW dividing the tile count, widest first; leftover waves split K
     if (ntiles % 16 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, ntiles / 16, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, ntiles / 16, st);
     if (ntiles % 12 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 3, 4>(a, N, ntiles / 12, st) : launch_cfg<DT, EPI, 4, 1, 3, 8>(a, N, ntiles / 12, st);
@@ -508,6 +511,7 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   if (!ly || !g || !x_slab || !h_out || !c_out || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!(ly->k & 1) || ly->k / 2 > g->P) return NINT_E_ARG;
+  if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
   if (!aligned16(x_slab) || !aligned16(h_prev) || !aligned16(ly->Wf) || !aligned16(h_out)) return NINT_E_ALIGN;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   if (ly->Cxp % kc || ly->Chp % kc || ly->Ch16 % 16 || ly->Chp < ly->Ch16) return NINT_E_ARG;
@@ -528,6 +532,7 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.bias = ly->bias_p;
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = (char*)h_out; a.gates_out = (char*)gates_out;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
+  a.tile_rows = ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st);
@@ -544,6 +549,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!dx_accum && !dh_prev) return NINT_OK;
   if (!aligned16(dG) || !aligned16(ly->Wd)) return NINT_E_ALIGN;
+  if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   const int Gc = 4 * ly->Ch16;
   ConvArgs a = {};
@@ -560,6 +566,10 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.out0 = (char*)dx_accum; a.out1 = (char*)dh_prev;
   a.out0_overwrite = overwrite_dx ? 1 : 0;
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
+  a.tile_rows = ly->tile_rows;
+#ifdef NINT_EXPERIMENT
+  a.dbg = ly->reserved1;
+#endif
   // only the n-tiles whose destination exists are computed
   const int nt_x = ly->Cxp / 16, nt_h = ly->Chp / 16;
   a.nt_begin = dx_accum ? 0 : nt_x;

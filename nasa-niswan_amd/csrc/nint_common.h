@@ -122,6 +122,10 @@ struct ConvArgs {
   int k, p, taps;
   int H, W, P, Hh, Wh;
   int tiles_x, tiles_y;
+  int tile_rows;         // 0 = per launch shape, 4 / 8 = forced tile height
+#ifdef NINT_EXPERIMENT
+  int dbg;               // experiment build only: tile-configuration selector (nint_layer.reserved1)
+#endif
   int cpf;               // channel chunks per LDS A fill
   int a_bytes;           // bytes reserved for the A image
   int nhp_pad;           // halo-tile pixels rounded up to 16 (one g-plane of the A image)
@@ -144,8 +148,8 @@ struct ConvArgs {
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                      float* db_partial, bool dc_zero, void* stream);
-int nint_internal_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
-                                     const void* dG, const void* x_slab, const void* h_slab, float* partial,
-                                     size_t partial_bytes, int n_cu, int h_skip, void* stream);
+int nint_internal_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, const void* x_slab,
+                             const void* h_slab, float* dW, float* db, float* partial, size_t partial_bytes, int n_cu,
+                             const float* db_partial, int db_rows, int h_skip, void* stream);
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
                              void* dh_prev, bool overwrite_dx, void* stream);

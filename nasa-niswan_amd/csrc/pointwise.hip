@@ -33,10 +33,85 @@ __global__ void pack_btchw_kernel(const float* __restrict__ src, void* __restric
   }
 }
 
+// Stage C rows of W floats (one per channel, each contiguous along x) into the LDS tile [C][ld]: the tile is
+// walked as C * (W / VW) vectors of VW floats; a thread issues the loads of U vectors BEFORE the first LDS store, so
+// U * 256 independent loads are in flight per workgroup (the rows are read once, from HBM: latency, not issue,
+// bounds this loop).  rowfn(c) -> (pointer to the row, mean, std, output channel); ZS = z-score the values.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+template <int VW> struct RowVec;
+template <> struct RowVec<1> { typedef float type; };
+template <> struct RowVec<2> { typedef f32x2_t type; };
+template <> struct RowVec<4> { typedef f32x4_t type; };
+struct RowDesc { const float* p; float mean, sd; int co; };
+
+template <int VW, bool ZS, class RowFn>
+__device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, int C, int W, RowFn rowfn) {
+  typedef typename RowVec<VW>::type V;
+  constexpr int U = VW == 4 ? 4 : 8;
+  const int WV = W / VW, total = C * WV;
+  const unsigned magic = (unsigned)(((1ull << 32) + WV - 1) / WV);   // idx / WV by multiply-high: exact for idx < 65536, WV <= 4096
+  const bool small = total < 65536 && WV <= 4096;
+  for (int base = threadIdx.x; base < total; base += 256 * U) {
+    V v[U];
+    RowDesc d[U];
+    int q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256;
+      if (idx < total) {
+        const int c = small ? (int)__umulhi((unsigned)idx, magic) : idx / WV;
+        q[u] = idx - c * WV;
+        d[u] = rowfn(c);
+        v[u] = *(const V*)(d[u].p + q[u] * VW);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base + u * 256 < total) {
+        float* trow = tile + d[u].co * ld + q[u] * VW;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          float f;
+          if constexpr (VW == 1) f = v[u]; else f = v[u][e];
+          trow[e] = ZS ? (f - d[u].mean) / d[u].sd : f;
+        }
+      }
+    }
+  }
+}
+
+// write one row of Wo pixels from the tile as 16-byte vectors of 8 (bf16) / 4 (f32) consecutive channels;
+// xmap(xo) = tile column of output pixel xo
+template <int DT, class XMap>
+__device__ __forceinline__ void write_row_channels_last(const float* __restrict__ tile, int ld, int C, int Cp, int Wo, char* __restrict__ d,
+                                                        XMap xmap) {
+  constexpr int V = 16 / Elem<DT>::ES;         // channels per 16-byte vector
+  const int nv = Cp / V;
+  for (int i = threadIdx.x; i < Wo * nv; i += 256) {
+    const int xo = i / nv, v = i - xo * nv;
+    const int xs = xmap(xo);
+    float f[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = v * V + j;
+      f[j] = c < C ? tile[c * ld + xs] : 0.f;
+    }
+    u32x4_t o;
+    if constexpr (DT == NINT_BF16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(uint32_t, f[j]);
+    }
+    *(u32x4_t*)(d + ((size_t)xo * Cp + v * V) * Elem<DT>::ES) = o;
+  }
+}
+
 // Tiled variant: one workgroup per (b, t, y) row.  The NCHW side is read along x (full cache
 // lines per channel row), transposed through LDS, and the channels-last side is written as
 // 16-byte vectors of 8 (bf16) / 4 (f32) consecutive channels, i.e. whole 64-byte-chunk rows.
-template <int DT>
+template <int DT, int VW>
 __global__ __launch_bounds__(256) void pack_btchw_rows_kernel(const float* __restrict__ src, void* __restrict__ dst,
                                                              int B, int T, int C, int Cp, int H, int W, int P, int Hh,
                                                              int Wh) {
@@ -47,32 +122,11 @@ __global__ __launch_bounds__(256) void pack_btchw_rows_kernel(const float* __res
   const int t = r % T;
   const int b = r / T;
   const float* s = src + (((size_t)b * T + t) * C) * H * W + (size_t)y * W;
-  for (int i = threadIdx.x; i < C * W; i += 256) {
-    const int c = i / W, x = i - c * W;
-    tile[c * ld + x] = s[(size_t)c * H * W + x];
-  }
+  const size_t HW = (size_t)H * W;
+  stage_rows<VW, false>(tile, ld, C, W, [&](int c) { return RowDesc{s + c * HW, 0.f, 1.f, c}; });
   __syncthreads();
-  constexpr int V = 16 / Elem<DT>::ES;         // channels per 16-byte vector
-  const int nv = Cp / V;
   char* d = (char*)dst + ((((size_t)t * B + b) * Hh + (y + P)) * Wh + P) * (size_t)Cp * Elem<DT>::ES;
-  for (int i = threadIdx.x; i < W * nv; i += 256) {
-    const int x = i / nv, v = i - x * nv;
-    float f[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const int c = v * V + j;
-      f[j] = c < C ? tile[c * ld + x] : 0.f;
-    }
-    u32x4_t o;
-    if constexpr (DT == NINT_BF16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (uint32_t)f2bf(f[2 * j]) | ((uint32_t)f2bf(f[2 * j + 1]) << 16);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(uint32_t, f[j]);
-    }
-    *(u32x4_t*)(d + ((size_t)x * Cp + v * V) * Elem<DT>::ES) = o;
-  }
+  write_row_channels_last<DT>(tile, ld, C, Cp, W, d, [](int x) { return x; });
 }
 
 template <int DT>
@@ -127,10 +181,13 @@ extern "C" int nint_pack_btchw(const float* src, void* dst, int B, int T, int C,
   const size_t tile_bytes = (size_t)C * (g->W + 1) * sizeof(float);
   if (tile_bytes <= 64 * 1024 && Cp % (dtype == NINT_BF16 ? 8 : 4) == 0) {
     const dim3 grid((unsigned)((size_t)B * T * g->H));
-    if (dtype == NINT_BF16)
-      hipLaunchKernelGGL(pack_btchw_rows_kernel<NINT_BF16>, grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
-    else
-      hipLaunchKernelGGL(pack_btchw_rows_kernel<NINT_F32>, grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+    // widest row vector the alignment of every channel row allows (rows start at multiples of W floats)
+    const int vw = ((((uintptr_t)src) & 15) == 0 && g->W % 4 == 0) ? 4 : (((((uintptr_t)src) & 7) == 0 && g->W % 2 == 0) ? 2 : 1);
+#define NINT_PACK(DT_, VW_) hipLaunchKernelGGL((pack_btchw_rows_kernel<DT_, VW_>), grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, \
+                                               g->H, g->W, g->P, g->Hh, g->Wh)
+    if (dtype == NINT_BF16) { if (vw == 4) NINT_PACK(NINT_BF16, 4); else if (vw == 2) NINT_PACK(NINT_BF16, 2); else NINT_PACK(NINT_BF16, 1); }
+    else { if (vw == 4) NINT_PACK(NINT_F32, 4); else if (vw == 2) NINT_PACK(NINT_F32, 2); else NINT_PACK(NINT_F32, 1); }
+#undef NINT_PACK
     NINT_LAUNCH_CHECK();
     return NINT_OK;
   }
@@ -848,11 +905,13 @@ __global__ __launch_bounds__(256) void preproc_nchw_kernel(PreArgs a, const floa
 // channels-last ET with the channel padding written as zeros.  One workgroup per (b, t, yp) row: the C source
 // rows (each contiguous along x) are z-scored into an LDS tile [C][W+1], then written out as 16-byte vectors of
 // 8 (bf16) / 4 (f32) consecutive channels -- the f32 NCHW intermediate and the separate pack pass never exist.
-template <int DT>
+template <int DT, int VW>
 __global__ __launch_bounds__(256) void preproc_slab_kernel(PreArgs a, const float* __restrict__ mean, const float* __restrict__ stdv,
                                                            void* __restrict__ dst, int B, int b0, int nb, int T, int C, int Cp,
                                                            int H, int W, int Hp, int Wp, int mode, int P, int Hh, int Wh) {
-  extern __shared__ float tile[];              // [C][W + 1]
+  extern __shared__ __attribute__((aligned(16))) char smem_pre[];
+  RowDesc* rows = (RowDesc*)smem_pre;                                        // [C] source row of every fused channel
+  float* tile = (float*)(smem_pre + nint_round_up(C * (int)sizeof(RowDesc), 16));   // [C][W + 1]
   const int ld = W + 1;
   const int pl = (Wp - W) / 2, pt = (Hp - H) / 2, pb = Hp - H - pt;
   int r = blockIdx.x;
@@ -861,43 +920,20 @@ __global__ __launch_bounds__(256) void preproc_slab_kernel(PreArgs a, const floa
   const int b = r / T;                         // sample inside this launch, [0, nb)
   bool flip;
   const int ys = pre_src_row(yp, H, pt, pb, mode, &flip);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int s = 0; s < a.nsrc; ++s) {
-    const int nlev = a.first_c[s + 1] - a.first_c[s];
-    const float* plane0 = a.src[s] + ((size_t)(a.t0[b] + t) * nlev) * H * W + (size_t)ys * W;
-    for (int lev = wave; lev < nlev; lev += 4) {          // a wave per source row
-      const int cs = a.first_c[s] + lev;
-      const int co = flip ? C - 1 - cs : cs;              // output channel fed by this source channel
-      const float mm = mean[cs], ss = stdv[cs];
-      const float* row = plane0 + (size_t)lev * H * W;
-      float* trow = tile + co * ld;
-      for (int x = lane; x < W; x += 64) trow[x] = (row[x] - mm) / ss;
-    }
+  for (int cs = threadIdx.x; cs < C; cs += 256) {   // one descriptor per source channel: (source, level) found once per row block
+    int s, lev, nlev;
+    pre_find(a, cs, &s, &lev, &nlev);
+    rows[cs] = RowDesc{a.src[s] + ((size_t)(a.t0[b] + t) * nlev + lev) * H * W + (size_t)ys * W, mean[cs], stdv[cs],
+                       flip ? C - 1 - cs : cs};
   }
   __syncthreads();
-  constexpr int V = 16 / Elem<DT>::ES;         // channels per 16-byte vector
-  const int nv = Cp / V;
+  stage_rows<VW, true>(tile, ld, C, W, [&](int c) { return rows[c]; });
+  __syncthreads();
   char* d = (char*)dst + ((((size_t)t * B + b0 + b) * Hh + (yp + P)) * Wh + P) * (size_t)Cp * Elem<DT>::ES;
-  for (int i = threadIdx.x; i < Wp * nv; i += 256) {
-    const int xp = i / nv, v = i - xp * nv;
-    int xs = xp - pl;
-    xs = xs < 0 ? xs + W : (xs >= W ? xs - W : xs);
-    float f[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const int c = v * V + j;
-      f[j] = c < C ? tile[c * ld + xs] : 0.f;
-    }
-    u32x4_t o;
-    if constexpr (DT == NINT_BF16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(uint32_t, f[j]);
-    }
-    *(u32x4_t*)(d + ((size_t)xp * Cp + v * V) * Elem<DT>::ES) = o;
-  }
+  write_row_channels_last<DT>(tile, ld, C, Cp, Wp, d, [&](int xp) {
+    const int xs = xp - pl;                    // cyclic longitude (dataset.py:67-80)
+    return xs < 0 ? xs + W : (xs >= W ? xs - W : xs);
+  });
 }
 
 static int pre_args(PreArgs* a, const float* const* srcs, const int* lev, int nsrc, int H, int W, int Hp, int Wp, int mode) {
@@ -960,8 +996,14 @@ extern "C" int nint_preproc_fuse_pad_slab(const float* const* srcs, const int* l
   if (C < 0) return C;
   if (Cxp < C || Cxp % (dtype == NINT_BF16 ? 8 : 4)) return NINT_E_ARG;
   if ((((uintptr_t)xs_slab) & 15) != 0) return NINT_E_ALIGN;
-  const size_t tile_bytes = (size_t)C * (W + 1) * sizeof(float);
+  const size_t tile_bytes = nint_round_up(C * (int)sizeof(RowDesc), 16) + (size_t)C * (W + 1) * sizeof(float);
   if (tile_bytes > 160 * 1024) return NINT_E_LDS;
+  // widest row vector every source row's alignment allows (rows start at multiples of W floats from the record base)
+  int vw = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1);
+  for (int i = 0; i < nsrc; ++i) {
+    const uintptr_t p = (uintptr_t)srcs[i];
+    while (vw > 1 && (p & (4 * vw - 1))) vw >>= 1;
+  }
   hipStream_t st = (hipStream_t)stream;
   for (int b0 = 0; b0 < B; b0 += PRE_MAX_B) {
     const int nb = B - b0 < PRE_MAX_B ? B - b0 : PRE_MAX_B;
@@ -970,16 +1012,18 @@ extern "C" int nint_preproc_fuse_pad_slab(const float* const* srcs, const int* l
       a.t0[i] = t0[b0 + i];
     }
     const dim3 grid((unsigned)((size_t)nb * T * Hp));
-#define NINT_PRE(DT_)                                                                                                     \
+#define NINT_PRE_V(DT_, VW_)                                                                                              \
     {                                                                                                                     \
-      auto kern = preproc_slab_kernel<DT_>;                                                                               \
+      auto kern = preproc_slab_kernel<DT_, VW_>;                                                                          \
       if (tile_bytes > 64 * 1024)                                                                                         \
         NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes)); \
       hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, a, mean, stdv, xs_slab, B, b0, nb, T, C, Cxp, H, W, Hp, Wp, \
                          mode, g->P, g->Hh, g->Wh);                                                                        \
     }
+#define NINT_PRE(DT_) { if (vw == 4) NINT_PRE_V(DT_, 4) else if (vw == 2) NINT_PRE_V(DT_, 2) else NINT_PRE_V(DT_, 1) }
     if (dtype == NINT_BF16) NINT_PRE(NINT_BF16) else NINT_PRE(NINT_F32)
 #undef NINT_PRE
+#undef NINT_PRE_V
     NINT_LAUNCH_CHECK();
   }
   return NINT_OK;

@@ -2,7 +2,6 @@
 // the hardware self-test, and the whole-sequence drivers that enqueue every launch of a
 // ConvLSTM forward (model.py:253-274) or its BPTT from C++ on one HIP stream, so the Python
 // side pays one ctypes call per pass instead of one per kernel.
-#include <stdlib.h>
 #include <string.h>
 #include "nint_common.h"
 
@@ -90,56 +89,11 @@ extern "C" int nint_selftest(float* out, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ sequence drivers
-// Layer wavefront on HIP streams: cell (t, l) only depends on (t, l-1) and (t-1, l), so layer l runs
-// on its own stream and waits for ONE event per step (recorded by the neighbouring layer).  With
-// three layers up to three cells are in flight: the tail of one launch (962 workgroups on 512
-// slots) is filled by the next, narrow layers overlap with wide ones, and in the backward pass the
-// HBM-bound pointwise kernels overlap with the MFMA-bound dgrad kernels of the other layers.
-// Layer 0 stays on the caller's stream; every pass forks from and joins back into it, so the
-// caller (and torch's stream-ordered allocator) sees ordinary single-stream semantics.
-// Opt-in with NINT_STREAMS=1 in the environment; by default everything stays on the caller's stream.
+// Every launch of a pass is enqueued from C++ on the CALLER's stream, in dependency order.  The library owns no
+// streams, events or other state: measured on MI355X a (t, layer) wavefront on side streams and weight-gradient
+// reductions overlapped with the BPTT chain were both at or below this order (co-resident
+// MFMA-bound kernels evict each other's LDS / register budget), so they are not shipped.
 static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
-
-struct StreamPool {
-  bool ready = false, enabled = true;
-  hipStream_t side[NINT_MAX_LAYERS] = {};
-  hipEvent_t ev[NINT_MAX_LAYERS] = {};     // "latest cell of layer l done"
-  hipStream_t wg[NINT_MAX_LAYERS] = {};    // low-priority streams of the chunked weight-gradient launches
-  hipEvent_t evw[NINT_MAX_LAYERS] = {};
-  hipEvent_t fork = nullptr;
-};
-static StreamPool g_pool[16];
-
-static int pool_get(StreamPool** out) {
-  int dev = 0;
-  NINT_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return NINT_E_ARG;
-  StreamPool& p = g_pool[dev];
-  if (!p.ready) {
-    // opt-in: with the current kernels (3 workgroups per CU, short launches) the wavefront measures
-    // within noise of the single-stream order on MI355X, so the simpler order is the default
-    const char* e = getenv("NINT_STREAMS");
-    p.enabled = (e && e[0] == '1');
-    int prio_least = 0, prio_greatest = 0;
-    NINT_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    for (int l = 0; l < NINT_MAX_LAYERS; ++l) {
-      NINT_CHECK_HIP(hipStreamCreateWithFlags(&p.side[l], hipStreamNonBlocking));
-      NINT_CHECK_HIP(hipEventCreateWithFlags(&p.ev[l], hipEventDisableTiming));
-      // the weight-gradient chunks are throughput filler behind the latency-critical BPTT chain
-      NINT_CHECK_HIP(hipStreamCreateWithPriority(&p.wg[l], hipStreamNonBlocking, prio_least));
-      NINT_CHECK_HIP(hipEventCreateWithFlags(&p.evw[l], hipEventDisableTiming));
-    }
-    NINT_CHECK_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
-    p.ready = true;
-  }
-  *out = &p;
-  return NINT_OK;
-}
-
-static bool wavefront_env() {   // EXPERIMENT
-  static const bool v = [] { const char* e = getenv("NINT_WAVEFRONT"); return !(e && e[0] == '0'); }();
-  return v;
-}
 
 static int seq_check(const nint_seq* s) {
   if (!s || s->L < 1 || s->L > NINT_MAX_LAYERS || s->B < 1 || s->T < 1) return NINT_E_ARG;
@@ -152,41 +106,13 @@ static int seq_check(const nint_seq* s) {
   return NINT_OK;
 }
 
-// fork: side streams wait for everything already enqueued on the caller's stream
-static int fork_streams(StreamPool* p, hipStream_t st0, hipStream_t* S, int L, bool multi) {
-  S[0] = st0;
-  for (int l = 1; l < L; ++l) S[l] = multi ? p->side[l] : st0;
-  if (multi) {
-    NINT_CHECK_HIP(hipEventRecord(p->fork, st0));
-    for (int l = 1; l < L; ++l) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], p->fork, 0));
-  }
-  return NINT_OK;
-}
-
-// join: the caller's stream waits for the last launch of every side stream
-static int join_streams(StreamPool* p, hipStream_t st0, hipStream_t* S, int L, bool multi) {
-  if (!multi) return NINT_OK;
-  for (int l = 1; l < L; ++l) {
-    NINT_CHECK_HIP(hipEventRecord(p->ev[l], S[l]));
-    NINT_CHECK_HIP(hipStreamWaitEvent(st0, p->ev[l], 0));
-  }
-  return NINT_OK;
-}
-
 extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   int rc = seq_check(s);
-  if (rc != NINT_OK) return rc;
-  StreamPool* pool = nullptr;
-  rc = pool_get(&pool);
   if (rc != NINT_OK) return rc;
   const nint_geom* g = &s->g;
   const size_t es = esize(s->dtype);
   const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
   const int B = s->B, L = s->L;
-  const bool multi = pool->enabled && L > 1 && wavefront_env();
-  hipStream_t S[NINT_MAX_LAYERS];
-  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi);
-  if (rc != NINT_OK) return rc;
   for (int t = 0; t < s->T; ++t) {                               // model.py:265
     for (int l = 0; l < L; ++l) {                                // model.py:267
       const nint_layer* ly = &s->layer[l];
@@ -201,21 +127,15 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
       char* h_out = (char*)s->h[l] + (size_t)(t + 1) * hs;
       float* c_out = s->c[l] + (size_t)(t + 1) * cs;
       char* gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
-      // (t, l) needs h of (t, l-1): the latest record of ev[l-1] is exactly that cell
-      if (multi && l > 0) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));
-      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, S[l]);
+      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
       if (rc != NINT_OK) return rc;
-      if (multi && l + 1 < L) NINT_CHECK_HIP(hipEventRecord(pool->ev[l], S[l]));
     }
   }
-  return join_streams(pool, (hipStream_t)stream, S, L, multi);
+  return NINT_OK;
 }
 
 extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   int rc = seq_check(s);
-  if (rc != NINT_OK) return rc;
-  StreamPool* pool = nullptr;
-  rc = pool_get(&pool);
   if (rc != NINT_OK) return rc;
   const nint_geom* g = &s->g;
   const size_t es = esize(s->dtype);
@@ -225,30 +145,6 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     if (!s->gates[l] || !s->dG[l] || !s->dh[l] || !s->dc[l] || !s->dW[l] || !s->db[l]) return NINT_E_ARG;
   if (s->need_dx && !s->dx) return NINT_E_ARG;
   if (!s->wg_partial) return NINT_E_ARG;
-  // Weight gradients are reduced in NCH time chunks: chunk c (time steps [T*c/NCH, T*(c+1)/NCH)) is
-  // launched on a low-priority stream as soon as BPTT has passed its first time step, so most of the
-  // weight-gradient work runs inside the idle phases of the remaining (latency-bound) BPTT chain.
-  // Each (layer, chunk) has its own split-K workspace.
-  // NINT_WG_CHUNKS (environment) = number of time chunks, 1..NINT_WGRAD_CHUNKS; default 1: measured on
-  // MI355X the chunk launches steal CU slots from the BPTT chain and lengthen the step
-  static const int nch_env = [] { const char* e = getenv("NINT_WG_CHUNKS"); int v = e ? atoi(e) : 1;
-                                  return v < 1 ? 1 : (v > NINT_WGRAD_CHUNKS ? NINT_WGRAD_CHUNKS : v); }();
-  int nch = s->T < nch_env ? s->T : nch_env;
-  size_t wg_stride[NINT_MAX_LAYERS], wg_off[NINT_MAX_LAYERS], wg_need = 0;
-  for (int l = 0; l < L; ++l) {
-    wg_stride[l] = (nint_wgrad_workspace_bytes(&s->layer[l], s->dtype, s->n_cu) + 255) / 256 * 256;
-    wg_off[l] = wg_need;
-    wg_need += wg_stride[l] * nch;
-  }
-  const bool multi = pool->enabled && wg_need <= s->wg_partial_bytes;
-  if (!multi) nch = 1;
-  const int chunk_steps = nint_cdiv(s->T, nch);          // time steps per chunk (the last may be shorter)
-  nch = nint_cdiv(s->T, chunk_steps);
-  const int N_plan = chunk_steps * B;
-  hipStream_t S[NINT_MAX_LAYERS];
-  rc = fork_streams(pool, (hipStream_t)stream, S, L, multi && L > 1 && wavefront_env());
-  if (rc != NINT_OK) return rc;
-  const bool wave = multi && L > 1 && wavefront_env();    // layer wavefront on side streams
 
   for (int t = s->T - 1; t >= 0; --t) {
     for (int l = L - 1; l >= 0; --l) {
@@ -260,67 +156,34 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // bias-gradient partial rows of this (t, l): fused into the pointwise pass when the shape allows
       float* dbp = (s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0)
                        ? s->db_partial[l] + (size_t)t * NINT_DB_ROWS * Gc : nullptr;
-      // dh[l] is complete once dgrad(t, l+1) has added its x columns: latest record of ev[l+1]
-      if (wave && l + 1 < L) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l + 1], 0));
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
       const bool first = t == s->T - 1;
       rc = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
-                                            s->dh[l], s->dc[l], dG, dbp, first && ((s->zero_dstate >> (2 * l)) & 1), S[l]);
+                                            s->dh[l], s->dc[l], dG, dbp, first && ((s->zero_dstate >> (2 * l)) & 1), stream);
       if (rc != NINT_OK) return rc;
       void* dx_accum = (l > 0) ? s->dh[l - 1]
                                : (s->need_dx ? (void*)((char*)s->dx + (size_t)t * B * comp_px * ly->Cxp * es) : nullptr);
       // at t == 0 with a zero initial state nobody consumes d/dh_{-1}
       void* dh_prev = (t == 0 && !s->has_init_state) ? nullptr : s->dh[l];
-      // the += into dh[l-1] must follow dgrad(t+1, l-1)'s store: at this point of the enqueue order
-      // that is the latest record of ev[l-1] (none yet at t = T-1: the fork covers it)
-      if (wave && l > 0 && t < s->T - 1) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], pool->ev[l - 1], 0));
       // the x columns overwrite instead of accumulate where the destination is known to be zero: dx (every time
       // step has its own slab, written once) and, at the first step, a dh[l-1] flagged zero
       const bool ow = l == 0 ? true : (first && ((s->zero_dstate >> (2 * (l - 1) + 1)) & 1));
-      rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, ow, S[l]);
+      rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, ow, stream);
       if (rc != NINT_OK) return rc;
-      if (wave) NINT_CHECK_HIP(hipEventRecord(pool->ev[l], S[l]));
-      if (multi && nch > 1 && t % chunk_steps == 0) {
-        // dG[l] of chunk c = t / chunk_steps is complete: reduce it now, behind the rest of BPTT
-        const int c = t / chunk_steps;
-        const int t_hi = (t + chunk_steps < s->T) ? t + chunk_steps : s->T;
-        NINT_CHECK_HIP(hipEventRecord(pool->evw[l], S[l]));
-        NINT_CHECK_HIP(hipStreamWaitEvent(pool->wg[l], pool->evw[l], 0));
-        const char* x_all = (l == 0) ? (const char*)s->xs
-                                     : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
-        rc = nint_internal_conv_wgrad_partial(ly, g, s->dtype, N_plan, t * B, (t_hi - t) * B, s->dG[l], x_all, s->h[l],
-                                              (float*)((char*)s->wg_partial + wg_off[l] + (size_t)c * wg_stride[l]), wg_stride[l],
-                                              s->n_cu, (t == 0 && !s->has_init_state) ? B : 0, pool->wg[l]);
-        if (rc != NINT_OK) return rc;
-      }
     }
   }
-  // fold the chunks (and the bias-gradient partial rows) of every layer
+  // weight / bias gradients: ONE reduction over all T time steps per layer and source
   for (int l = 0; l < L; ++l) {
     const nint_layer* ly = &s->layer[l];
     const bool fused_db = s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0;
-    if (multi && nch > 1) {
-      rc = nint_conv_wgrad_finalize(ly, g, s->dtype, N_plan, nch, wg_stride[l] / sizeof(float), s->T * B, s->dG[l], s->dW[l],
-                                    s->db[l], (float*)((char*)s->wg_partial + wg_off[l]), s->n_cu,
-                                    fused_db ? s->db_partial[l] : nullptr, s->T * NINT_DB_ROWS, pool->wg[l]);
-      if (rc != NINT_OK) return rc;
-      NINT_CHECK_HIP(hipEventRecord(pool->evw[l], pool->wg[l]));
-      NINT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, pool->evw[l], 0));
-    } else {
-      const char* x_all = (l == 0) ? (const char*)s->xs
-                                   : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
-      // with the layer wavefront the three launches run concurrently: each layer has its own workspace
-      float* part = wave ? (float*)((char*)s->wg_partial + wg_off[l]) : s->wg_partial;
-      const size_t part_bytes = wave ? wg_stride[l] : s->wg_partial_bytes;
-      // h_{-1} = 0 for a sequence from the zero state: the h part of the reduction skips time step 0
-      rc = nint_internal_conv_wgrad_partial(ly, g, s->dtype, s->T * B, 0, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */,
-                                            part, part_bytes, s->n_cu, s->has_init_state ? 0 : B, S[l]);
-      if (rc != NINT_OK) return rc;
-      rc = nint_conv_wgrad_finalize(ly, g, s->dtype, s->T * B, 1, 0, s->T * B, s->dG[l], s->dW[l], s->db[l], part, s->n_cu,
-                                    fused_db ? s->db_partial[l] : nullptr, s->T * NINT_DB_ROWS, S[l]);
-      if (rc != NINT_OK) return rc;
-    }
+    const char* x_all = (l == 0) ? (const char*)s->xs
+                                 : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
+    // h_{-1} = 0 for a sequence from the zero state: the h part of the reduction skips time step 0
+    rc = nint_internal_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
+                                  s->wg_partial, s->wg_partial_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
+                                  s->T * NINT_DB_ROWS, s->has_init_state ? 0 : B, stream);
+    if (rc != NINT_OK) return rc;
   }
-  return join_streams(pool, (hipStream_t)stream, S, L, wave);
+  return NINT_OK;
 }

@@ -16,7 +16,6 @@
 // Each workgroup keeps its 64 x (16*NTC*taps) output block in accumulators for its whole pixel
 // range and writes ONE partial slab; a second kernel folds the slabs in fixed order
 // (bitwise reproducible, no float atomics) into the OIHW gradient.
-#include <stdlib.h>
 #include "nint_common.h"
 
 struct WgradArgs {
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // spreads the splits over its blockDim/64 waves; the per-wave sums are folded through LDS.  The order is a
 // fixed function of the launch shape (bitwise reproducible); only the single write per weight is scattered.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Cx, int Ch, int Ch16, int k,
-                                    int NB, int CB, int NTC, int splits, int is_h, int nchunks, size_t chunk_stride) {
+                                    int NB, int CB, int NTC, int splits, int is_h) {
   __shared__ float red[1024];
   const int taps = k * k, Ctot = Cx + Ch;
   const int J = taps * NTC;
@@ -266,11 +265,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, G = blockDim.x >> 6;
   const size_t i = (size_t)blockIdx.x * 64 + lane;       // slab is a multiple of 1024: no tail
   float s = 0.f;
-  for (int ch_ = 0; ch_ < nchunks; ++ch_) {
-    const float* src = part + ch_ * chunk_stride + i;
 #pragma unroll 4
-    for (int sp = grp; sp < splits; sp += G) s += src[(size_t)sp * slab];
-  }
+  for (int sp = grp; sp < splits; sp += G) s += part[i + (size_t)sp * slab];
   red[threadIdx.x] = s;
   __syncthreads();
   if (grp != 0) return;
@@ -348,7 +344,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 
 // ------------------------------------------------------------------------------ host side
 struct WgPlan {
-  int NTC, J, JW, NS, NB, CBx, CBh, splits_x, splits_h, tiles_x, tiles_y, ntiles, tps_x, tps_h;
+  int NTC, J, JW, NB, CBx, CBh, splits_x, splits_h, tiles_x, tiles_y, ntiles, tps_x, tps_h;
   size_t off_h, off_db, total_floats;
   int db_rows;
 };
@@ -358,12 +354,9 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   if (ly->k != 1 && ly->k != 3 && ly->k != 5) return NINT_E_SHAPE;
   pl->NTC = (taps * 2 <= 20 && ly->Cxp % 32 == 0 && ly->Chp % 32 == 0) ? 2 : 1;
   pl->J = taps * pl->NTC;
-  // wave split: (NS row groups) x (4/NS column groups of JW columns); NINT_WG_NS=1|2 overrides
-  static const int ns_env = [] { const char* e = getenv("NINT_WG_NS"); return e ? atoi(e) : 0; }();
-  pl->NS = ns_env == 1 || ns_env == 2 ? ns_env : 1;   // NS=2 measured slower for 25 taps (register spills), equal for 9
-  if (pl->NS == 2 && ly->k == 1) pl->NS = 1;
-  if (pl->NS == 2) { pl->JW = (pl->J + 1) / 2; if (pl->JW > 13) return NINT_E_SHAPE; pl->JW = pl->JW <= 9 ? 9 : 13; }
-  else { pl->JW = pl->J <= 20 ? 5 : 7; if (pl->J > 4 * pl->JW) return NINT_E_SHAPE; }
+  // every wave owns all 4 row tiles (64 gate columns) and a quarter of the (tap, channel-tile) columns
+  pl->JW = pl->J <= 20 ? 5 : 7;
+  if (pl->J > 4 * pl->JW) return NINT_E_SHAPE;
   const int CW = 16 * pl->NTC;
   if (ly->Cxp % CW || ly->Chp % CW) return NINT_E_SHAPE;
   pl->NB = 4 * ly->Ch16 / 64;
@@ -374,11 +367,10 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   pl->tiles_y = g ? nint_cdiv(g->H, PR) : 1;
   pl->ntiles = g ? N * pl->tiles_x * pl->tiles_y : (1 << 30);
   if (n_cu <= 0) n_cu = 256;
-  static const int occ_env = [] { const char* e = getenv("NINT_WG_OCC"); return e ? atoi(e) : 2; }();   // EXPERIMENT
   auto splits_for = [&](int CB) {
     // two workgroups per CU in flight, but never fewer than 32 pixel tiles per split: the
     // accumulator flush (J KiB-tiles per workgroup) must stay small against the K work
-    int s = nint_cdiv(occ_env * n_cu, pl->NB * CB);
+    int s = nint_cdiv(2 * n_cu, pl->NB * CB);
     if (s > pl->ntiles / 32) s = pl->ntiles / 32;
     if (s < 1) s = 1;
     return s;
@@ -402,23 +394,21 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
 extern "C" size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, int n_cu) {
   if (!ly) return 0;
   WgPlan pl;
-  // upper bound independent of N: splits are capped by 3*n_cu / blocks
+  // upper bound independent of N: splits are capped by 2*n_cu / blocks
   if (wg_plan(ly, dtype, n_cu, 1, nullptr, &pl) != NINT_OK) return 0;
   return pl.total_floats * sizeof(float);
 }
 
-template <int DT, int JW, int NS, int KS, int NTCT>
+template <int DT, int JW, int KS, int NTCT>
 static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   typedef WgTile<DT> TT;
   const int p = a.p;
   const int a_bytes = TT::PR * 32 * TT::RA;
   const int b_bytes = nint_round_up((TT::PR + 2 * p) * (32 + 2 * p) * TT::rb(a.NTC), 1024);   // whole 1-KiB DMA pieces
-  size_t lds = 2 * (size_t)(a_bytes + b_bytes);
-  static const int occ_env = [] { const char* e = getenv("NINT_WG_OCC"); return e ? atoi(e) : 2; }();   // EXPERIMENT
-  if (occ_env == 1 && lds < 82 * 1024) lds = 82 * 1024;   // one workgroup per CU: leave room for the BPTT chain
+  const size_t lds = 2 * (size_t)(a_bytes + b_bytes);
   if (lds > 160 * 1024) return NINT_E_LDS;
   if (a.k != KS || a.NTC != NTCT) return NINT_E_ARG;
-  auto kern = wgrad_kernel<DT, JW, NS, KS, NTCT>;
+  auto kern = wgrad_kernel<DT, JW, 1, KS, NTCT>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(splits, nblk), dim3(256), lds, st, a);
@@ -426,42 +416,30 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   return NINT_OK;
 }
 
-// instantiated (kernel size, channel tiles, columns per wave, wave split) combinations
+// instantiated (kernel size, channel tiles, columns per wave) combinations
 template <int DT>
 static int dispatch_wgrad(WgradArgs& a, const WgPlan& pl, int splits, int nblk, hipStream_t st) {
-  const int key = a.k * 1000 + a.NTC * 100 + pl.JW * 2 + (pl.NS - 1);
+  const int key = a.k * 1000 + a.NTC * 100 + pl.JW;
   switch (key) {
-    case 5 * 1000 + 1 * 100 + 7 * 2 + 0: return launch_wgrad<DT, 7, 1, 5, 1>(a, splits, nblk, st);
-    case 5 * 1000 + 1 * 100 + 13 * 2 + 1: return launch_wgrad<DT, 13, 2, 5, 1>(a, splits, nblk, st);
-    case 3 * 1000 + 2 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 3, 2>(a, splits, nblk, st);
-    case 3 * 1000 + 2 * 100 + 9 * 2 + 1: return launch_wgrad<DT, 9, 2, 3, 2>(a, splits, nblk, st);
-    case 3 * 1000 + 1 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 3, 1>(a, splits, nblk, st);
-    case 3 * 1000 + 1 * 100 + 9 * 2 + 1: return launch_wgrad<DT, 9, 2, 3, 1>(a, splits, nblk, st);
-    case 1 * 1000 + 2 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 1, 2>(a, splits, nblk, st);
-    case 1 * 1000 + 1 * 100 + 5 * 2 + 0: return launch_wgrad<DT, 5, 1, 1, 1>(a, splits, nblk, st);
+    case 5 * 1000 + 1 * 100 + 7: return launch_wgrad<DT, 7, 5, 1>(a, splits, nblk, st);
+    case 3 * 1000 + 2 * 100 + 5: return launch_wgrad<DT, 5, 3, 2>(a, splits, nblk, st);
+    case 3 * 1000 + 1 * 100 + 5: return launch_wgrad<DT, 5, 3, 1>(a, splits, nblk, st);
+    case 1 * 1000 + 2 * 100 + 5: return launch_wgrad<DT, 5, 1, 2>(a, splits, nblk, st);
+    case 1 * 1000 + 1 * 100 + 5: return launch_wgrad<DT, 5, 1, 1>(a, splits, nblk, st);
     default: return NINT_E_SHAPE;
   }
 }
 
-// One chunk of a (possibly time-chunked) weight-gradient reduction: images [n_first, n_first+N) of the
-// stacks, split-K slabs written to `partial` with the layout of the plan for N_plan images (so that
-// every chunk of a reduction has the same layout and nint_conv_wgrad_finalize can fold them).
-extern "C" int nint_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
-                                       const void* dG, const void* x_slab, const void* h_slab, float* partial,
-                                       size_t partial_bytes, int n_cu, void* stream) {
-  return nint_internal_conv_wgrad_partial(ly, g, dtype, N_plan, n_first, N, dG, x_slab, h_slab, partial, partial_bytes, n_cu, 0, stream);
-}
-
-// h_skip: the first h_skip images of this chunk have an identically zero h source (h_{-1} = 0 of a sequence that
-// starts from the zero state, model.py:259-262): the h part skips them -- 1/T of its work.
-int nint_internal_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int n_first, int N,
-                                     const void* dG, const void* x_slab, const void* h_slab, float* partial,
-                                     size_t partial_bytes, int n_cu, int h_skip, void* stream) {
+// h_skip: the first h_skip images have an identically zero h source (h_{-1} = 0 of a sequence that starts from
+// the zero state, model.py:259-262): the h part skips them -- 1/T of its work.
+int nint_internal_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, const void* x_slab,
+                             const void* h_slab, float* dW, float* db, float* partial, size_t partial_bytes, int n_cu,
+                             const float* db_partial, int db_rows, int h_skip, void* stream) {
+  if (!ly || !g || !dG || !x_slab || !h_slab || !dW || !db || !partial || N <= 0) return NINT_E_ARG;
   if (h_skip < 0 || h_skip > N) return NINT_E_ARG;
-  if (!ly || !g || !dG || !x_slab || !h_slab || !partial || N <= 0 || N_plan < N || n_first < 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   WgPlan pl;
-  int rc = wg_plan(ly, dtype, n_cu, N_plan, g, &pl);
+  int rc = wg_plan(ly, dtype, n_cu, N, g, &pl);
   if (rc != NINT_OK) return rc;
   if (pl.total_floats * sizeof(float) > partial_bytes) return NINT_E_ARG;
   const int es = dtype == NINT_BF16 ? 2 : 4;
@@ -472,58 +450,44 @@ int nint_internal_conv_wgrad_partial(const nint_layer* ly, const nint_geom* g, i
     a.dG_pix_stride = Gc * es;
     a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
     const int skip = part == 1 ? h_skip : 0;
-    a.dG = (const char*)dG + (size_t)(n_first + skip) * a.dG_img_stride;
+    a.dG = (const char*)dG + (size_t)skip * a.dG_img_stride;
     const int Cp = part == 0 ? ly->Cxp : ly->Chp;
     a.src_pix_stride = Cp * es;
     a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
-    a.src = (const char*)(part == 0 ? x_slab : h_slab) + (size_t)(n_first + skip) * a.src_img_stride;
+    a.src = (const char*)(part == 0 ? x_slab : h_slab) + (size_t)skip * a.src_img_stride;
     a.partial = partial + (part == 0 ? 0 : pl.off_h);
     a.CB = part == 0 ? pl.CBx : pl.CBh;
     a.NTC = pl.NTC; a.J = pl.J;
     a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
     a.P = g->P; a.Wh = g->Wh;
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
-    a.ntiles = (N - skip) * pl.tiles_x * pl.tiles_y;  // this chunk; empty splits flush zeros
+    a.ntiles = (N - skip) * pl.tiles_x * pl.tiles_y;  // empty splits flush zeros
     const int splits = part == 0 ? pl.splits_x : pl.splits_h;
     a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, splits) : 1;   // spread what is there evenly over the planned splits
     const int nblk = pl.NB * a.CB;
     rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, pl, splits, nblk, st) : dispatch_wgrad<NINT_F32>(a, pl, splits, nblk, st);
     if (rc != NINT_OK) return rc;
   }
-  return NINT_OK;
-}
-
-// Fold the slabs of `nchunks` chunks (chunk c at partial + c*chunk_stride_floats) into dW, and the
-// bias gradient from the fused pointwise partial rows (or a column-sum pass over dG).
-extern "C" int nint_conv_wgrad_finalize(const nint_layer* ly, const nint_geom* g, int dtype, int N_plan, int nchunks,
-                                        size_t chunk_stride_floats, int N_total, const void* dG, float* dW, float* db,
-                                        float* partial, int n_cu, const float* db_partial, int db_rows, void* stream) {
-  if (!ly || !g || !dW || !db || !partial || nchunks < 1 || N_plan <= 0) return NINT_E_ARG;
-  if (!db_partial && !dG) return NINT_E_ARG;
-  WgPlan pl;
-  int rc = wg_plan(ly, dtype, n_cu, N_plan, g, &pl);
-  if (rc != NINT_OK) return rc;
-  const int Gc = 4 * ly->Ch16;
-  hipStream_t st = (hipStream_t)stream;
+  // fold the split-K slabs into dW, and the bias gradient from the fused pointwise partial rows (or a column-sum pass over dG)
   for (int part = 0; part < 2; ++part) {
     const int CB = part == 0 ? pl.CBx : pl.CBh;
     const size_t slab = (size_t)pl.NB * CB * pl.J * 1024;
     const int splits = part == 0 ? pl.splits_x : pl.splits_h;
     // few large slabs: 4 waves share the splits; many small slabs: 16 waves
-    const int threads = splits * nchunks >= 64 ? 1024 : 256;
+    const int threads = splits >= 64 ? 1024 : 256;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(slab / 64)), dim3(threads), 0, st, partial + (part == 0 ? 0 : pl.off_h), dW,
-                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, splits, part, nchunks, chunk_stride_floats);
+                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, splits, part);
     NINT_LAUNCH_CHECK();
   }
   {
-    float* dbp = partial + pl.off_db;          // (chunk 0's tail is the scratch of the bias fold)
+    float* dbp = partial + pl.off_db;          // (the workspace's tail is the scratch of the bias fold)
     dim3 grid(pl.db_rows, Gc / 64);
     if (db_partial) {
       hipLaunchKernelGGL(rowsum_partial_kernel, dim3(Gc / 64, pl.db_rows), dim3(1024), 0, st, db_partial, dbp, db_rows, Gc);
     } else if (dtype == NINT_BF16) {
-      hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N_total, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+      hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
     } else {
-      hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N_total, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+      hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
     }
     NINT_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(nint_cdiv(4 * ly->Ch, 64)), dim3(1024), 0, st, dbp, db, ly->Ch, Gc, pl.db_rows);
@@ -535,8 +499,6 @@ extern "C" int nint_conv_wgrad_finalize(const nint_layer* ly, const nint_geom* g
 extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG,
                                const void* x_slab, const void* h_slab, float* dW, float* db, float* partial,
                                size_t partial_bytes, int n_cu, const float* db_partial, int db_rows, void* stream) {
-  if (!dW || !db) return NINT_E_ARG;
-  int rc = nint_conv_wgrad_partial(ly, g, dtype, N, 0, N, dG, x_slab, h_slab, partial, partial_bytes, n_cu, stream);
-  if (rc != NINT_OK) return rc;
-  return nint_conv_wgrad_finalize(ly, g, dtype, N, 1, 0, N, dG, dW, db, partial, n_cu, db_partial, db_rows, stream);
+  return nint_internal_conv_wgrad(ly, g, dtype, N, dG, x_slab, h_slab, dW, db, partial, partial_bytes, n_cu, db_partial, db_rows, 0,
+                                  stream);
 }

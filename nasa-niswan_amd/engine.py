@@ -12,6 +12,10 @@ import torch
 from . import _lib
 from ._lib import NINT_BF16, NINT_F32, NintGeom, NintLayer, NintSeq, check, ptr, stream_ptr
 
+# 0: the library picks the gate / dgrad pixel-tile height per launch shape; 4 or 8 forces it for every layer of
+# engines built afterwards (nint_layer.tile_rows) -- how the tests run both heights on every shape
+FORCE_TILE_ROWS = 0
+
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
 
 
@@ -131,9 +135,9 @@ class SeqEngine:
             ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k = cfg.Cx, Cxp, cfg.Ch, Ch16, Chp, cfg.k
             ly.Wf, ly.Wd, ly.bias_p = self.Wf[-1].data_ptr(), self.Wd[-1].data_ptr(), self.bias_p[-1].data_ptr()
             self.layers.append(ly)
-            # split-K workspaces: one per layer and time chunk (256-byte aligned), so that the weight-gradient
-            # launches of different layers / chunks may overlap with each other and with the rest of BPTT
-            wg_bytes += _lib.NINT_WGRAD_CHUNKS * ((self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256)
+            ly.tile_rows = FORCE_TILE_ROWS
+            # one split-K workspace serves every layer in turn (the reductions run back to back on one stream)
+            wg_bytes = max(wg_bytes, (self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256)
         # shapes the weight-gradient kernel has no instantiation for: known NOW, reported at the first training
         # workspace (forward / inference work for every odd k) instead of as a shape error in the first backward()
         self.train_unsupported = self.untrainable_layers(self.cfgs, self.dt, self.n_cu)

@@ -129,3 +129,13 @@ def test_untrainable_kernel_sizes_are_known_before_any_backward():
     assert SeqEngine.untrainable_layers([LayerCfg(5, 64, 5), LayerCfg(64, 32, 3), LayerCfg(32, 16, 1)], "bf16") == []
     bad = SeqEngine.untrainable_layers([LayerCfg(5, 16, 3), LayerCfg(16, 8, 7)], "f32")
     assert len(bad) == 1 and "layer 1" in bad[0] and "k=7" in bad[0]
+
+
+def test_library_reads_no_environment_and_owns_no_streams():
+    """nint.h promises a stateless library: no hidden process-global switches.  The shared object must not import
+    getenv, and must not create streams or events of its own (every launch goes to the caller's stream)."""
+    from nasa_niswan_amd import _lib
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH], text=True)
+    for sym in ("getenv", "secure_getenv", "hipStreamCreate", "hipStreamCreateWithFlags", "hipStreamCreateWithPriority",
+                "hipEventCreate", "hipEventCreateWithFlags"):
+        assert not re.search(rf"\b{sym}\b", und), f"libnint_hip.so imports {sym}"

@@ -316,18 +316,19 @@ def test_bf16_tracks_f32_along_a_training_trajectory(pkg):
     assert worst_loss <= 1e-2 and worst_cos >= 0.995 and last < 0.97 * first
 
 
-@pytest.mark.parametrize("env", [{"NINT_STREAMS": "1", "NINT_WG_CHUNKS": "2"}, {"NINT_MT": "4"}, {"NINT_MT": "8"}, {"NINT_WG_NS": "2"}],
-                         ids=["layer-wavefront+chunked-wgrad", "all-4-row-tiles", "all-8-row-tiles", "wgrad-2x2-wave-split"])
-def test_opt_in_schedules_and_tile_heights_keep_parity(pkg, env):
-    """The launch-shape switches are read once per process, so the model-level parity tests are
-    re-run in a child process under each setting: multi-stream layer wavefront with time-chunked weight
-    gradients, and both tile heights forced for every layer."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        "-k", "model_forward_backward or input_gradient or cell_forward_backward"],
-                       cwd=root, env=e, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("rows", [4, 8])
+def test_both_tile_heights_keep_parity_on_every_shape(pkg, rows):
+    """The gate / dgrad kernels pick 4- or 8-row pixel tiles per launch shape.  The choice is an explicit field of the
+    layer descriptor (nint_layer.tile_rows; the library reads no environment and keeps no state): both heights are
+    forced here for every layer of ragged, multi-layer and reference-size shapes and checked against the oracle."""
+    from nasa_niswan_amd import engine
+    from test_gpu_shapes import CASES, check, run_case
+    engine.FORCE_TILE_ROWS = rows
+    try:
+        for name in ("ragged-grid-odd-channels", "k1-and-k3", "wide-hidden-48"):
+            for dtype in ("f32", "bf16"):
+                check(run_case(pkg, *CASES[name], dtype), dtype)
+        check(run_case(pkg, 5, [64, 32, 16], [5, 3, 3], 1, 2, 2, 20, 36, "f32"), "f32")      # the reference stack
+        check(run_case(pkg, 62, [64, 32, 16], [5, 3, 3], 20, 1, 2, 100, 154, "bf16"), "bf16")  # bench geometry, T=2
+    finally:
+        engine.FORCE_TILE_ROWS = 0
