@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 104
+#define NINT_VERSION 105
 #define NINT_DB_ROWS 1024   /* rows of bias-gradient partials one fused pointwise-backward launch writes */
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
@@ -61,7 +61,10 @@ typedef struct nint_layer {
   int32_t Ch, Ch16, Chp;  /* hidden channels / padded to 16 / padded to KC */
   int32_t k;              /* odd kernel size, padding k/2 (model.py:204) */
   int32_t tile_rows;      /* rows of the gate / dgrad kernels' pixel tile: 0 = chosen per launch shape, or 4 / 8 */
-  int32_t reserved1;
+  int32_t xfold;          /* 1: the x source is HORIZONTALLY FOLDED (thin inputs, first layer only): slab channel
+                           * kx*Cx + c holds x[.., x + kx - k/2][c] (0 outside the image), Cxp = roundup(k*Cx, KC), and
+                           * the x part of K is k vertical taps x k*Cx channels instead of k*k taps x Cx channels padded
+                           * to KC each (reference layer 0: Conv2d(5+64 -> 256, k=5), model.py:207-211: 5 x-steps, not 25) */
   const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */
   const void* Wd;         /* dgrad weights (transposed + flipped), ET */
   const float* bias_p;    /* bias permuted to gate-stash column order [4*Ch16] */
@@ -113,6 +116,13 @@ int nint_geom_make(nint_geom* g /*host*/, int H, int W, int P);
  * `x[:, t]` slicing of model.py:266 and torch.cat of model.py:219 (never materialised). */
 int nint_pack_btchw(const float* src, void* dst, int B, int T, int C, int Cp, const nint_geom* g,
                     int dtype, void* stream);
+/* the same into a HORIZONTALLY FOLDED slab (nint_layer.xfold): channel kx*C + c of pixel x holds src[.., x + kx - k/2]
+ * (zero outside the image: the convolution's own zero padding), Cp >= k*C */
+int nint_pack_btchw_xfold(const float* src, void* dst, int B, int T, int C, int k, int Cp, const nint_geom* g,
+                          int dtype, void* stream);
+/* backward of that fold: compact ET slab [N][H][W][Cp] of d/d(folded x) -> d/dx (N,C,H,W) f32,
+ * dx[c][x] = sum_kx dfold[x - kx + k/2][kx*C + c] */
+int nint_unfold_dx(const void* src, float* dst, int N, int C, int k, int Cp, int H, int W, int dtype, void* stream);
 /* halo slab images [n0, n0+N) -> (N,C,H,W) f32 */
 int nint_unpack_halo(const void* src, float* dst, int n0, int N, int C, int Cp, const nint_geom* g,
                      int dtype, void* stream);
@@ -121,12 +131,15 @@ int nint_pack_compact(const float* src, void* dst, int N, int C, int Cp, int H, 
 int nint_unpack_compact(const void* src, float* dst, int N, int C, int Cp, int H, int W, int dtype, void* stream);
 
 /* ---- weights ----------------------------------------------------------------------------- */
-/* bytes of the packed fwd / dgrad weight images of one layer */
-size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int dgrad);
+/* 1 when horizontally folding the x source of a (first) layer lowers its number of K-steps:
+ * ceil(k*Cx / KC) * k < ceil(Cx / KC) * k * k  (see nint_layer.xfold); pure host arithmetic */
+int nint_xfold_pays(int Cx, int k, int dtype);
+/* bytes to reserve for EACH of the packed fwd / dgrad weight images of one layer */
+size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int xfold);
 /* W (4Ch, Cx+Ch, k, k) f32 OIHW + bias (4Ch) as nn.Conv2d stores them (model.py:207-211)
  * -> Wf, Wd (fragment order, ET) and bias_p.  Must be re-run after every optimiser step. */
 int nint_pack_weights(const float* W, const float* bias, void* Wf, void* Wd, float* bias_p,
-                      int Cx, int Ch, int k, int dtype, void* stream);
+                      int Cx, int Ch, int k, int xfold, int dtype, void* stream);
 
 /* ---- the hot path: one cell step ----------------------------------------------------------- */
 /* ConvLSTMCell.forward (model.py:216-231): gates = conv(cat[x,h]) ; sigmoid/tanh ; c,h update,
@@ -219,8 +232,8 @@ int nint_preproc_fuse_pad_batch(const float* const* srcs /*host*/, const int* le
                                 int T, int H, int W, int Hp, int Wp, int mode, void* stream);
 int nint_preproc_fuse_pad_slab(const float* const* srcs /*host*/, const int* lev /*host*/, int nsrc,
                                const float* mean, const float* std, const int* t0 /*host*/, int B, void* xs_slab,
-                               int Cxp, int T, int H, int W, const nint_geom* g /*host*/, int mode, int dtype,
-                               void* stream);
+                               int Cxp, int xfold_k /* 0: plain slab; k: horizontally folded for kernel size k */,
+                               int T, int H, int W, const nint_geom* g /*host*/, int mode, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

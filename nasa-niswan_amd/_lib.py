@@ -25,7 +25,7 @@ class NintGeom(C.Structure):
 
 class NintLayer(C.Structure):
     _fields_ = [("Cx", C.c_int32), ("Cxp", C.c_int32), ("Ch", C.c_int32), ("Ch16", C.c_int32), ("Chp", C.c_int32),
-                ("k", C.c_int32), ("tile_rows", C.c_int32), ("reserved1", C.c_int32),
+                ("k", C.c_int32), ("tile_rows", C.c_int32), ("xfold", C.c_int32),
                 ("Wf", vp), ("Wd", vp), ("bias_p", vp)]
 
 
@@ -54,7 +54,10 @@ SIGNATURES = {
     "nint_pack_compact": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, vp]),
     "nint_unpack_compact": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, vp]),
     "nint_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
-    "nint_pack_weights": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, vp]),
+    "nint_xfold_pays": (_I, [_I, _I, _I]),
+    "nint_pack_weights": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, _I, vp]),
+    "nint_pack_btchw_xfold": (_I, [vp, vp, _I, _I, _I, _I, _I, _PG, _I, vp]),
+    "nint_unfold_dx": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, _I, vp]),
     "nint_cell_fwd": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
     "nint_cell_bwd_pointwise": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nint_conv_dgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp]),
@@ -68,7 +71,7 @@ SIGNATURES = {
     "nint_adam_flat": (_I, [vp, vp, vp, vp, _SZ, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, vp]),
     "nint_preproc_fuse_pad": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, vp, _I, _I, _I, _I, _I, _I, vp]),
     "nint_preproc_fuse_pad_batch": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, C.POINTER(_I), _I, vp, _I, _I, _I, _I, _I, _I, vp]),
-    "nint_preproc_fuse_pad_slab": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, C.POINTER(_I), _I, vp, _I, _I, _I, _I, _PG, _I, _I, vp]),
+    "nint_preproc_fuse_pad_slab": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, C.POINTER(_I), _I, vp, _I, _I, _I, _I, _I, _PG, _I, _I, vp]),
 }
 
 _lib = None
@@ -92,7 +95,7 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nint_version() != 104:
+    if lib.nint_version() != 105:
         raise NintError("libnint_hip.so version mismatch")
     _lib = lib
     return lib

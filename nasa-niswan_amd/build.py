@@ -28,7 +28,7 @@ def _newer(a, bs):
 
 def build(force: bool = False, verbose: bool = False, exp: bool = False) -> str:
     """exp=True: the EXPERIMENT build (-DNINT_EXPERIMENT: extra tile configurations selectable through
-    nint_layer.reserved1 for tools/kbench.py) into libnint_hip_exp.so; never loaded by the package itself."""
+    the upper bits of nint_layer.tile_rows for tools/kbench.py) into libnint_hip_exp.so; never loaded by the package itself."""
     global OBJ, LIB, FLAGS
     if exp:
         OBJ, LIB = os.path.join(HERE, "build_exp"), os.path.join(HERE, "libnint_hip_exp.so")

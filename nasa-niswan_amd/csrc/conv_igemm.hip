@@ -150,14 +150,27 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(smem + (size_t)ub * 16), 16, 0, 0);
     }
-    // ---- this wave's K-slice of the fill: steps [s_lo, s_hi) of c_cnt*taps ----
-    const int nsteps = c_cnt * taps;
+    // K-steps of this fill in two SEGMENTS: chunks of a horizontally folded source 0 (nint_layer.xfold: channel =
+    // (kx, c), so only the k vertical taps of the halo tile's centre column remain: kx0 = 1) and all other chunks
+    // (k x k taps).  Without folding segment 0 is empty and everything below is the one-segment loop.
+    const int n0f = a.kx0 == k ? 0 : min(max(a.nchunk0 - c_begin, 0), c_cnt);   // folded chunks in this fill
+    const int steps_before = min(c_begin, a.nchunk0) * k * a.kx0 + max(c_begin - a.nchunk0, 0) * taps;   // K-steps of chunks [0, c_begin)
+    bool synced = false;
+    for (int seg = 0; seg < 2; ++seg) {
+    const int cs_lo = seg == 0 ? 0 : n0f, cs_n = seg == 0 ? n0f : c_cnt - n0f;
+    if (cs_n == 0) continue;
+    const int kx = seg == 0 ? a.kx0 : k;       // horizontal taps of this segment
+    const int xoff = kx == k ? 0 : p;          // folded: the centre column
+    const int tps = k * kx;
+    // ---- this wave's K-slice of the segment: steps [s_lo, s_hi) of cs_n*tps ----
+    const int nsteps = cs_n * tps;
     const int s_lo = (nsteps * wk) / WK, s_hi = (nsteps * (wk + 1)) / WK;
-    int cl = s_lo / taps;
-    int tap = s_lo - cl * taps;
-    int tyy = tap / k;
-    int txx = tap - tyy * k;
-    const char* Bs = Bwave + (size_t)(c_begin * taps + s_lo) * bstep;
+    int cl = s_lo / tps;
+    int tap = s_lo - cl * tps;
+    cl += cs_lo;
+    int tyy = tap / kx;
+    int txx = tap - tyy * kx;
+    const char* Bs = Bwave + (size_t)(steps_before + (seg == 0 ? 0 : n0f * k * a.kx0) + s_lo) * bstep;
     // B ring: BD K-steps of weight fragments in flight per wave (L2 latency under load is several
     // K-steps long and only two waves share a SIMD, so one step of prefetch is not enough)
     // The ring loop is kept BRANCH-FREE (reloads are unconditional; past the slice's last step the pointer
@@ -175,8 +188,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
         NINT_B_ADVANCE()
       }
     }
-    __syncthreads();                           // image visible to all waves
-    if (c_begin == 0) { NINT_STAMP_AT(1) }
+    if (!synced) {
+      __syncthreads();                         // image visible to all waves
+      synced = true;
+      if (c_begin == 0) { NINT_STAMP_AT(1) }
+    }
     // MT >= 8 (two workgroups per CU): the A fragments are software-pipelined in groups of AG rows through
     // two register groups -- while the AG*NTW MFMAs of one group run, the reads of the group after next
     // are in flight -- so that a wave alone on its SIMD keeps the matrix pipe busy.  (Left to itself the
@@ -190,9 +206,9 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       constexpr int LA = NBUF - 1;
       static_assert(MT % AG == 0 && LA >= 1 && LA <= NG && (NG * BD) % NBUF == 0, "group rotation must close over the unrolled ring");
       u32x4_t ax[NBUF * AG];
-      int va = (int)(cl * chunk_bytes + (tyy * HWt + txx) * 16) + a_lane_off;   // LDS byte offset of this step's fragment (row 0)
-      const int d_row = (HWt - (k - 1)) * 16;                                  // tap (ty, k-1) -> (ty+1, 0)
-      const int d_chunk = chunk_bytes - ((k - 1) * HWt + (k - 1)) * 16;        // tap (k-1, k-1) -> next chunk, tap (0, 0)
+      int va = (int)(cl * chunk_bytes + (tyy * HWt + txx + xoff) * 16) + a_lane_off;   // LDS byte offset of this step's fragment (row 0)
+      const int d_row = (HWt - (kx - 1)) * 16;                                 // tap (ty, kx-1) -> (ty+1, 0)
+      const int d_chunk = chunk_bytes - ((k - 1) * HWt + (kx - 1)) * 16;       // tap (k-1, kx-1) -> next chunk, tap (0, 0)
       if (s_lo < s_hi) {
 #pragma unroll
         for (int i = 0; i < LA * AG; ++i) ax[i] = *(const u32x4_t*)(smem + va + rowoff[i]);
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       {                                                                                                    \
         /* branch-free tap advance: the next step's base is this one plus one of three constants */       \
         const bool m_ = (MORE);                                                                            \
-        const bool wx_ = txx + 1 == k;                                                                     \
+        const bool wx_ = txx + 1 == kx;                                                                    \
         const bool wy_ = wx_ && (tyy + 1 == k);                                                            \
         const int dl_ = wy_ ? d_chunk : (wx_ ? d_row : 16);                                                \
         const int vn = va + (m_ ? dl_ : 0);    /* (this step's again at the slice end) */                  \
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
       for (; s + BD <= s_hi; s += BD) {
 #pragma unroll
         for (int d = 0; d < BD; ++d) {
-          const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
+          const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx + xoff) * 16 + a_lane_off;
           u32x4_t af[MT];
 #pragma unroll
           for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
@@ -258,14 +274,14 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
 #pragma unroll
           for (int j = 0; j < NTW; ++j) bq[d][j] = *(const u32x4_t*)(Bn + blane + j * 1024);
           NINT_B_ADVANCE()
-          if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+          if (++txx == kx) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
         }
       }
       // remainder (< BD steps): ring slots 0.. already hold exactly these steps
 #pragma unroll
       for (int d = 0; d < BD - 1; ++d) {
         if (s + d < s_hi) {
-          const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx) * 16 + a_lane_off;
+          const char* Ab = smem + (size_t)cl * chunk_bytes + (tyy * HWt + txx + xoff) * 16 + a_lane_off;
           u32x4_t af[MT];
 #pragma unroll
           for (int i = 0; i < MT; ++i) af[i] = *(const u32x4_t*)(Ab + rowoff[i]);
@@ -273,10 +289,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<DT>(bq[d][j], af[i], acc[i][j]);   // swapped: D[channel][pixel]
-          if (++txx == k) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
+          if (++txx == kx) { txx = 0; if (++tyy == k) { tyy = 0; ++cl; } }
         }
       }
     }
+    }   // segment
   }
 
 #undef NINT_B_ADVANCE
@@ -478,7 +495,8 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   if (ntiles <= 0) return NINT_OK;
   // short-K launches (narrow layers) take 4-row tiles; nint_layer.tile_rows = 4 | 8 overrides (tests run both
   // heights on every shape)
-  const bool mt4 = a.tile_rows ? a.tile_rows == 4 : ((a.nchunk0 + a.nchunk1) * a.taps <= 48 || ntiles <= 4);
+  const int ksteps = a.nchunk0 * a.k * a.kx0 + a.nchunk1 * a.taps;
+  const bool mt4 = a.tile_rows ? a.tile_rows == 4 : (ksteps <= 48 || ntiles <= 4);
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;
@@ -511,10 +529,13 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   if (!ly || !g || !x_slab || !h_out || !c_out || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!(ly->k & 1) || ly->k / 2 > g->P) return NINT_E_ARG;
+#ifndef NINT_EXPERIMENT
   if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
+#endif
   if (!aligned16(x_slab) || !aligned16(h_prev) || !aligned16(ly->Wf) || !aligned16(h_out)) return NINT_E_ALIGN;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   if (ly->Cxp % kc || ly->Chp % kc || ly->Ch16 % 16 || ly->Chp < ly->Ch16) return NINT_E_ARG;
+  if ((ly->xfold != 0 && ly->xfold != 1) || (ly->xfold && ly->Cxp < ly->k * ly->Cx)) return NINT_E_ARG;
   ConvArgs a = {};
   a.src0 = (const char*)x_slab;
   a.src1 = (const char*)h_prev;
@@ -528,6 +549,7 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.NTt = 4 * ly->Ch16 / 16;
   a.nt_begin = 0;
   a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
+  a.kx0 = ly->xfold ? 1 : ly->k;              // horizontally folded x source: vertical taps only
   a.H = g->H; a.W = g->W; a.P = g->P; a.Hh = g->Hh; a.Wh = g->Wh;
   a.bias = ly->bias_p;
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = (char*)h_out; a.gates_out = (char*)gates_out;
@@ -549,7 +571,9 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!dx_accum && !dh_prev) return NINT_OK;
   if (!aligned16(dG) || !aligned16(ly->Wd)) return NINT_E_ALIGN;
+#ifndef NINT_EXPERIMENT
   if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
+#endif
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   const int Gc = 4 * ly->Ch16;
   ConvArgs a = {};
@@ -562,13 +586,15 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.Bp = (const char*)ly->Wd;
   a.NTt = (ly->Cxp + ly->Chp) / 16;
   a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
+  a.kx0 = ly->k;                              // the dG source always has all k x k taps (a folded x only zeroes weights)
   a.H = g->H; a.W = g->W; a.P = g->P; a.Hh = g->Hh; a.Wh = g->Wh;
   a.out0 = (char*)dx_accum; a.out1 = (char*)dh_prev;
   a.out0_overwrite = overwrite_dx ? 1 : 0;
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
   a.tile_rows = ly->tile_rows;
 #ifdef NINT_EXPERIMENT
-  a.dbg = ly->reserved1;
+  a.dbg = ly->tile_rows >> 8;                 // experiment build: selector in the upper bits
+  a.tile_rows = ly->tile_rows & 0xff;
 #endif
   // only the n-tiles whose destination exists are computed
   const int nt_x = ly->Cxp / 16, nt_h = ly->Chp / 16;

@@ -120,11 +120,12 @@ struct ConvArgs {
   int NTt;               // n-tiles per K-step in Bp
   int nt_begin;          // first n-tile this launch computes
   int k, p, taps;
+  int kx0;               // horizontal taps of src0: k, or 1 for a horizontally folded x source (nint_layer.xfold)
   int H, W, P, Hh, Wh;
   int tiles_x, tiles_y;
   int tile_rows;         // 0 = per launch shape, 4 / 8 = forced tile height
 #ifdef NINT_EXPERIMENT
-  int dbg;               // experiment build only: tile-configuration selector (nint_layer.reserved1)
+  int dbg;               // experiment build only: tile-configuration selector (upper bits of nint_layer.tile_rows)
 #endif
   int cpf;               // channel chunks per LDS A fill
   int a_bytes;           // bytes reserved for the A image

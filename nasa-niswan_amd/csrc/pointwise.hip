@@ -81,20 +81,32 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, int
 }
 
 // write one row of Wo pixels from the tile as 16-byte vectors of 8 (bf16) / 4 (f32) consecutive channels;
-// xmap(xo) = tile column of output pixel xo
+// xmap(xo) = tile column of output pixel xo.  kf > 1: HORIZONTALLY FOLDED output (nint_layer.xfold): output channel
+// kx*C + c of pixel xo is input channel c of pixel xo + kx - kf/2, zero outside [0, Wo) (the conv's zero padding).
 template <int DT, class XMap>
 __device__ __forceinline__ void write_row_channels_last(const float* __restrict__ tile, int ld, int C, int Cp, int Wo, char* __restrict__ d,
-                                                        XMap xmap) {
+                                                        XMap xmap, int kf = 1) {
   constexpr int V = 16 / Elem<DT>::ES;         // channels per 16-byte vector
   const int nv = Cp / V;
+  const unsigned magic_c = (unsigned)(((1ull << 32) + C - 1) / C);    // co / C by multiply-high (co < 65536)
   for (int i = threadIdx.x; i < Wo * nv; i += 256) {
     const int xo = i / nv, v = i - xo * nv;
-    const int xs = xmap(xo);
     float f[V];
+    if (kf <= 1) {
+      const int xs = xmap(xo);
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const int c = v * V + j;
-      f[j] = c < C ? tile[c * ld + xs] : 0.f;
+      for (int j = 0; j < V; ++j) {
+        const int c = v * V + j;
+        f[j] = c < C ? tile[c * ld + xs] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const int co = v * V + j;
+        const int kx = (int)__umulhi((unsigned)co, magic_c), c = co - kx * C;
+        const int xi = xo + kx - (kf >> 1);
+        f[j] = (kx < kf && xi >= 0 && xi < Wo) ? tile[c * ld + xmap(xi)] : 0.f;
+      }
     }
     u32x4_t o;
     if constexpr (DT == NINT_BF16) {
@@ -114,7 +126,7 @@ __device__ __forceinline__ void write_row_channels_last(const float* __restrict_
 template <int DT, int VW>
 __global__ __launch_bounds__(256) void pack_btchw_rows_kernel(const float* __restrict__ src, void* __restrict__ dst,
                                                              int B, int T, int C, int Cp, int H, int W, int P, int Hh,
-                                                             int Wh) {
+                                                             int Wh, int kf) {
   extern __shared__ float tile[];              // [C][W + 1]
   const int ld = W + 1;
   int r = blockIdx.x;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void pack_btchw_rows_kernel(const float* __res
   stage_rows<VW, false>(tile, ld, C, W, [&](int c) { return RowDesc{s + c * HW, 0.f, 1.f, c}; });
   __syncthreads();
   char* d = (char*)dst + ((((size_t)t * B + b) * Hh + (y + P)) * Wh + P) * (size_t)Cp * Elem<DT>::ES;
-  write_row_channels_last<DT>(tile, ld, C, Cp, W, d, [](int x) { return x; });
+  write_row_channels_last<DT>(tile, ld, C, Cp, W, d, [](int x) { return x; }, kf);
 }
 
 template <int DT>
@@ -172,9 +184,9 @@ __global__ void unpack_compact_kernel(const void* __restrict__ src, float* __res
   }
 }
 
-extern "C" int nint_pack_btchw(const float* src, void* dst, int B, int T, int C, int Cp, const nint_geom* g,
-                               int dtype, void* stream) {
-  if (!src || !dst || !g || B <= 0 || T <= 0 || C <= 0 || Cp < C) return NINT_E_ARG;
+static int pack_btchw_impl(const float* src, void* dst, int B, int T, int C, int kf, int Cp, const nint_geom* g, int dtype,
+                           void* stream) {
+  if (!src || !dst || !g || B <= 0 || T <= 0 || C <= 0 || Cp < C * kf) return NINT_E_ARG;
   const size_t total = (size_t)B * T * g->H * g->W * Cp;
   hipStream_t st = (hipStream_t)stream;
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
@@ -184,19 +196,58 @@ extern "C" int nint_pack_btchw(const float* src, void* dst, int B, int T, int C,
     // widest row vector the alignment of every channel row allows (rows start at multiples of W floats)
     const int vw = ((((uintptr_t)src) & 15) == 0 && g->W % 4 == 0) ? 4 : (((((uintptr_t)src) & 7) == 0 && g->W % 2 == 0) ? 2 : 1);
 #define NINT_PACK(DT_, VW_) hipLaunchKernelGGL((pack_btchw_rows_kernel<DT_, VW_>), grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, \
-                                               g->H, g->W, g->P, g->Hh, g->Wh)
+                                               g->H, g->W, g->P, g->Hh, g->Wh, kf)
     if (dtype == NINT_BF16) { if (vw == 4) NINT_PACK(NINT_BF16, 4); else if (vw == 2) NINT_PACK(NINT_BF16, 2); else NINT_PACK(NINT_BF16, 1); }
     else { if (vw == 4) NINT_PACK(NINT_F32, 4); else if (vw == 2) NINT_PACK(NINT_F32, 2); else NINT_PACK(NINT_F32, 1); }
 #undef NINT_PACK
     NINT_LAUNCH_CHECK();
     return NINT_OK;
   }
+  if (kf > 1) return NINT_E_LDS;               // (the folded layout only exists for thin inputs: the row tile always fits)
   if (dtype == NINT_BF16)
     hipLaunchKernelGGL(pack_btchw_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
-  else if (dtype == NINT_F32)
-    hipLaunchKernelGGL(pack_btchw_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
   else
-    return NINT_E_ARG;
+    hipLaunchKernelGGL(pack_btchw_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+extern "C" int nint_pack_btchw(const float* src, void* dst, int B, int T, int C, int Cp, const nint_geom* g,
+                               int dtype, void* stream) {
+  return pack_btchw_impl(src, dst, B, T, C, 1, Cp, g, dtype, stream);
+}
+
+extern "C" int nint_pack_btchw_xfold(const float* src, void* dst, int B, int T, int C, int k, int Cp, const nint_geom* g,
+                                     int dtype, void* stream) {
+  if (k < 1 || !(k & 1)) return NINT_E_ARG;
+  return pack_btchw_impl(src, dst, B, T, C, k, Cp, g, dtype, stream);
+}
+
+// d/dx from the gradient of a horizontally folded input: dx[n][c][y][x] = sum_kx dfold[n][y][x - kx + k/2][kx*C + c]
+template <int DT>
+__global__ void unfold_dx_kernel(const void* __restrict__ src, float* __restrict__ dst, int N, int C, int k, int Cp, int H, int W) {
+  const size_t total = (size_t)N * C * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    size_t r = i / W;
+    const int y = r % H; r /= H;
+    const int c = r % C;
+    const int n = r / C;
+    float acc = 0.f;
+    for (int kx = 0; kx < k; ++kx) {
+      const int xs = x - kx + k / 2;
+      if (xs >= 0 && xs < W) acc += load_elem<DT>(src, (((size_t)n * H + y) * W + xs) * Cp + kx * C + c);
+    }
+    dst[i] = acc;
+  }
+}
+
+extern "C" int nint_unfold_dx(const void* src, float* dst, int N, int C, int k, int Cp, int H, int W, int dtype, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || k < 1 || !(k & 1) || Cp < k * C || (dtype != NINT_F32 && dtype != NINT_BF16)) return NINT_E_ARG;
+  if (dtype == NINT_BF16)
+    hipLaunchKernelGGL(unfold_dx_kernel<NINT_BF16>, grid1d((size_t)N * C * H * W), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, k, Cp, H, W);
+  else
+    hipLaunchKernelGGL(unfold_dx_kernel<NINT_F32>, grid1d((size_t)N * C * H * W), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, k, Cp, H, W);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
@@ -237,19 +288,24 @@ extern "C" int nint_unpack_compact(const void* src, float* dst, int N, int C, in
 }
 
 // ------------------------------------------------------------------------------ weight packing
-// Fragment order: Bp[s][nt][lane][e]; s = chunk*taps + tap; lane = 16*g + col;
+// Fragment order: Bp[s][nt][lane][e]; s = K-step; lane = 16*g + col;
 // the lane's e-th element is K-channel chunk*KC + g*EPL + e and output column nt*16 + col.
-//   fwd  : K-channel -> cat[x,h] channel (x part padded to Cxp), column n' -> gate*Ch + cblock*16+col
+//   fwd  : K-steps = x chunks x taps, then h chunks x taps; K-channel -> cat[x,h] channel (x part padded to Cxp),
+//          column n' -> gate*Ch + cblock*16+col
 //   dgrad: K-channel -> gate column n' of dG, column -> cat channel, taps flipped
+// xfold (horizontally folded x source, nint_layer.xfold): the x chunks have k vertical taps only and their
+// K-channel kc = kx*Cx + c selects W[.][c][ky][kx]; in the dgrad image the folded x columns take their weight
+// at the centre-column taps (tx = k/2) and zero elsewhere.
 template <int DT>
 __global__ void pack_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias, void* __restrict__ Wf,
                                     void* __restrict__ Wd, float* __restrict__ bias_p, int Cx, int Cxp, int Ch, int Ch16,
-                                    int Chp, int k) {
+                                    int Chp, int k, int xfold) {
   typedef Elem<DT> E;
   const int taps = k * k;
   const int Ctot = Cx + Ch;
   const int ntf = 4 * Ch16 / 16;
-  const int sf = (Cxp + Chp) / E::KC * taps;
+  const int sx = Cxp / E::KC * (xfold ? k : taps);              // K-steps of the x part
+  const int sf = sx + Chp / E::KC * taps;
   const size_t nf = (size_t)sf * ntf * 64 * E::EPL;
   const int ntd = (Cxp + Chp) / 16;
   const int sd = 4 * Ch16 / E::KC * taps;
@@ -262,11 +318,26 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, const float* __
       const int lane = r % 64; r /= 64;
       const int nt = r % ntf;
       const int s = r / ntf;
-      const int chunk = s / taps, tap = s % taps;
-      const int kc = chunk * E::KC + (lane >> 4) * E::EPL + e;       // channel in padded cat space
-      int ic = -1;
-      if (kc < Cxp) { if (kc < Cx) ic = kc; }
-      else { const int hc = kc - Cxp; if (hc < Ch) ic = Cx + hc; }
+      const int kl = (lane >> 4) * E::EPL + e;                  // channel inside the chunk
+      int ic = -1, tap = 0;
+      if (s < sx) {
+        if (xfold) {
+          const int chunk = s / k, ky = s % k;
+          const int kc = chunk * E::KC + kl;                     // folded channel kx*Cx + c
+          if (kc < k * Cx) { ic = kc % Cx; tap = ky * k + kc / Cx; }
+        } else {
+          const int chunk = s / taps;
+          tap = s % taps;
+          const int kc = chunk * E::KC + kl;
+          if (kc < Cx) ic = kc;
+        }
+      } else {
+        const int sh = s - sx;
+        const int chunk = sh / taps;
+        tap = sh % taps;
+        const int hc = chunk * E::KC + kl;
+        if (hc < Ch) ic = Cx + hc;
+      }
       const int cblock = nt / 4, gate = nt % 4, col = lane & 15;
       const int ch = cblock * 16 + col;
       float v = 0.f;
@@ -284,11 +355,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, const float* __
       const int cblock = np / 64, gate = (np % 64) / 16, colk = np % 16;
       const int ch = cblock * 16 + colk;
       const int j = nt * 16 + (lane & 15);                           // cat channel (padded space)
-      int ic = -1;
-      if (j < Cxp) { if (j < Cx) ic = j; }
-      else { const int hc = j - Cxp; if (hc < Ch) ic = Cx + hc; }
       const int ty = tap / k, tx = tap % k;
-      const int ftap = (k - 1 - ty) * k + (k - 1 - tx);
+      int ic = -1;
+      int ftap = (k - 1 - ty) * k + (k - 1 - tx);
+      if (j < Cxp) {
+        if (xfold) {
+          if (j < k * Cx && tx == k / 2) { ic = j % Cx; ftap = (k - 1 - ty) * k + j / Cx; }
+        } else if (j < Cx) {
+          ic = j;
+        }
+      } else {
+        const int hc = j - Cxp;
+        if (hc < Ch) ic = Cx + hc;
+      }
       float v = 0.f;
       if (ic >= 0 && ch < Ch) v = W[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + ftap];
       store_elem<DT>(Wd, ii, v);
@@ -303,28 +382,34 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, const float* __
 
 extern "C" int nint_kc(int dtype) { return dtype == NINT_BF16 ? 32 : (dtype == NINT_F32 ? 16 : NINT_E_ARG); }
 
-extern "C" size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int dgrad) {
+// Folding pays when it lowers the number of x K-steps: ceil(k*Cx / KC) * k  <  ceil(Cx / KC) * k * k
+extern "C" int nint_xfold_pays(int Cx, int k, int dtype) {
+  const int kc = nint_kc(dtype);
+  if (kc < 0 || Cx <= 0 || k <= 1 || !(k & 1)) return 0;
+  return nint_cdiv(k * Cx, kc) < nint_cdiv(Cx, kc) * k ? 1 : 0;
+}
+
+extern "C" size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int xfold) {
   const int kc = nint_kc(dtype);
   if (kc < 0) return 0;
   const int es = dtype == NINT_BF16 ? 2 : 4;
-  const int Cxp = nint_round_up(Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
-  // both images hold (Cxp+Chp) x 4*Ch16 x taps elements
-  (void)dgrad;
+  const int Cxp = nint_round_up(xfold ? k * Cx : Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
+  // both images fit in (Cxp+Chp) x 4*Ch16 x taps elements (the folded forward image is smaller)
   return (size_t)(Cxp + Chp) * 4 * Ch16 * k * k * es;
 }
 
 extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, void* Wd, float* bias_p, int Cx,
-                                 int Ch, int k, int dtype, void* stream) {
-  if (!W || !Wf || !Wd || !bias_p || Cx <= 0 || Ch <= 0 || !(k & 1)) return NINT_E_ARG;
+                                 int Ch, int k, int xfold, int dtype, void* stream) {
+  if (!W || !Wf || !Wd || !bias_p || Cx <= 0 || Ch <= 0 || !(k & 1) || (xfold != 0 && xfold != 1)) return NINT_E_ARG;
   const int kc = nint_kc(dtype);
   if (kc < 0) return NINT_E_ARG;
-  const int Cxp = nint_round_up(Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
+  const int Cxp = nint_round_up(xfold ? k * Cx : Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
   const size_t n = 2 * (size_t)(Cxp + Chp) * 4 * Ch16 * k * k + 4 * Ch16;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == NINT_BF16)
-    hipLaunchKernelGGL(pack_weights_kernel<NINT_BF16>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k);
+    hipLaunchKernelGGL(pack_weights_kernel<NINT_BF16>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k, xfold);
   else
-    hipLaunchKernelGGL(pack_weights_kernel<NINT_F32>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k);
+    hipLaunchKernelGGL(pack_weights_kernel<NINT_F32>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k, xfold);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
@@ -908,7 +993,7 @@ __global__ __launch_bounds__(256) void preproc_nchw_kernel(PreArgs a, const floa
 template <int DT, int VW>
 __global__ __launch_bounds__(256) void preproc_slab_kernel(PreArgs a, const float* __restrict__ mean, const float* __restrict__ stdv,
                                                            void* __restrict__ dst, int B, int b0, int nb, int T, int C, int Cp,
-                                                           int H, int W, int Hp, int Wp, int mode, int P, int Hh, int Wh) {
+                                                           int H, int W, int Hp, int Wp, int mode, int P, int Hh, int Wh, int kf) {
   extern __shared__ __attribute__((aligned(16))) char smem_pre[];
   RowDesc* rows = (RowDesc*)smem_pre;                                        // [C] source row of every fused channel
   float* tile = (float*)(smem_pre + nint_round_up(C * (int)sizeof(RowDesc), 16));   // [C][W + 1]
@@ -933,7 +1018,7 @@ __global__ __launch_bounds__(256) void preproc_slab_kernel(PreArgs a, const floa
   write_row_channels_last<DT>(tile, ld, C, Cp, Wp, d, [&](int xp) {
     const int xs = xp - pl;                    // cyclic longitude (dataset.py:67-80)
     return xs < 0 ? xs + W : (xs >= W ? xs - W : xs);
-  });
+  }, kf);
 }
 
 static int pre_args(PreArgs* a, const float* const* srcs, const int* lev, int nsrc, int H, int W, int Hp, int Wp, int mode) {
@@ -986,15 +1071,17 @@ extern "C" int nint_preproc_fuse_pad(const float* const* srcs, const int* lev, i
 }
 
 extern "C" int nint_preproc_fuse_pad_slab(const float* const* srcs, const int* lev, int nsrc, const float* mean,
-                                          const float* stdv, const int* t0, int B, void* xs_slab, int Cxp, int T, int H,
-                                          int W, const nint_geom* g, int mode, int dtype, void* stream) {
+                                          const float* stdv, const int* t0, int B, void* xs_slab, int Cxp, int xfold_k,
+                                          int T, int H, int W, const nint_geom* g, int mode, int dtype, void* stream) {
   if (!mean || !stdv || !xs_slab || !t0 || !g || T <= 0 || B <= 0) return NINT_E_ARG;
+  if (xfold_k < 0 || (xfold_k > 1 && !(xfold_k & 1))) return NINT_E_ARG;
+  const int kf = xfold_k > 1 ? xfold_k : 1;
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
   const int Hp = g->H, Wp = g->W;               // the model runs on the padded grid (launcher.sh:24)
   PreArgs a;
   const int C = pre_args(&a, srcs, lev, nsrc, H, W, Hp, Wp, mode);
   if (C < 0) return C;
-  if (Cxp < C || Cxp % (dtype == NINT_BF16 ? 8 : 4)) return NINT_E_ARG;
+  if (Cxp < C * kf || Cxp % (dtype == NINT_BF16 ? 8 : 4)) return NINT_E_ARG;
   if ((((uintptr_t)xs_slab) & 15) != 0) return NINT_E_ALIGN;
   const size_t tile_bytes = nint_round_up(C * (int)sizeof(RowDesc), 16) + (size_t)C * (W + 1) * sizeof(float);
   if (tile_bytes > 160 * 1024) return NINT_E_LDS;
@@ -1018,7 +1105,7 @@ extern "C" int nint_preproc_fuse_pad_slab(const float* const* srcs, const int* l
       if (tile_bytes > 64 * 1024)                                                                                         \
         NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes)); \
       hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, a, mean, stdv, xs_slab, B, b0, nb, T, C, Cxp, H, W, Hp, Wp, \
-                         mode, g->P, g->Hh, g->Wh);                                                                        \
+                         mode, g->P, g->Hh, g->Wh, kf);                                                                    \
     }
 #define NINT_PRE(DT_) { if (vw == 4) NINT_PRE_V(DT_, 4) else if (vw == 2) NINT_PRE_V(DT_, 2) else NINT_PRE_V(DT_, 1) }
     if (dtype == NINT_BF16) NINT_PRE(NINT_BF16) else NINT_PRE(NINT_F32)

@@ -38,7 +38,9 @@ template <> struct WgTile<NINT_F32> { static constexpr int PR = 2, RA = 320; sta
 // KS (kernel size) and NTCT (channel tiles per column block) are template parameters so that every LDS
 // fragment address is `per-lane base VGPR + compile-time immediate`: the transposed reads then cost no
 // VALU instruction at all (the MFMAs leave only ~8 issue cycles each to the rest of the wave).
-template <int DT, int JW, int NS, int KS, int NTCT>
+// KX = horizontal taps of the source: KS, or 1 for a horizontally folded x source (nint_layer.xfold: its columns are
+// (vertical tap, folded channel tile) and every tap reads the centre column of the halo tile).
+template <int DT, int JW, int NS, int KS, int NTCT, int KX>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   typedef Elem<DT> E;
   typedef WgTile<DT> TT;
@@ -145,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   int vB[JW];
   int vA;
   const int nvalid = __builtin_amdgcn_readfirstlane(min(JW, max(0, a.J - j0)));   // real columns of this wave
-  constexpr int JT = KS * KS * NTCT;                                              // = a.J (host-checked)
+  constexpr int JT = KS * KX * NTCT;                                              // = a.J (host-checked)
+  constexpr int XO = KX == KS ? 0 : p;                                            // folded: the centre column
   constexpr int NVL = JT % JW == 0 ? JW : JT % JW;                                // columns of the last, partial group
   if constexpr (DT == NINT_BF16) {
     const int q = i16 >> 2, p8 = (i16 & 3) * 8;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     for (int jj = 0; jj < JW; ++jj) {
       const int j = min(j0 + jj, a.J - 1);
       const int tap = j / NTCT, ct = j - tap * NTCT;
-      const int tyy = tap / k, txx = tap - tyy * k;
+      const int tyy = tap / KX, txx = tap - tyy * KX + XO;
       vB[jj] = a_bytes + (tyy * HWt + txx + 4 * g + q) * RB + ct * 32 + p8;
     }
   } else {
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     for (int jj = 0; jj < JW; ++jj) {
       const int j = min(j0 + jj, a.J - 1);
       const int tap = j / NTCT, ct = j - tap * NTCT;
-      const int tyy = tap / k, txx = tap - tyy * k;
+      const int tyy = tap / KX, txx = tap - tyy * KX + XO;
       vB[jj] = a_bytes + (tyy * HWt + txx + g) * RB + (ct * 16 + i16) * 4;
     }
   }
@@ -257,10 +260,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // spreads the splits over its blockDim/64 waves; the per-wave sums are folded through LDS.  The order is a
 // fixed function of the launch shape (bitwise reproducible); only the single write per weight is scattered.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Cx, int Ch, int Ch16, int k,
-                                    int NB, int CB, int NTC, int splits, int is_h) {
+                                    int NB, int CB, int NTC, int J, int splits, int is_h, int xfold) {
   __shared__ float red[1024];
   const int taps = k * k, Ctot = Cx + Ch;
-  const int J = taps * NTC;
   const size_t slab = (size_t)NB * CB * J * 1024;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, G = blockDim.x >> 6;
   const size_t i = (size_t)blockIdx.x * 64 + lane;       // slab is a multiple of 1024: no tail
@@ -276,11 +278,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   const int j = r % J; r /= J;
   const int cb = r % CB;
   const int nb = r / CB;
-  const int tap = j / NTC, ct = j - tap * NTC;
-  const int cc = (cb * NTC + ct) * 16 + c16;          // channel inside this source
+  int tap = j / NTC;
+  const int ct = j - tap * NTC;
+  int cc = (cb * NTC + ct) * 16 + c16;                // channel inside this source
   const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
   const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
-  const int Csrc = is_h ? Ch : Cx;
+  int Csrc = is_h ? Ch : Cx;
+  if (!is_h && xfold) {                               // folded x source: column (ky, kx*Cx + c) -> W[.][c][ky][kx]
+    if (cc >= k * Cx) return;
+    tap = tap * k + cc / Cx;
+    cc = cc % Cx;
+  }
   if (cc >= Csrc || ch >= Ch) return;                 // padding rows / columns
   const int ic = is_h ? Cx + cc : cc;
   dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
@@ -343,51 +351,49 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 }
 
 // ------------------------------------------------------------------------------ host side
+struct WgPart { int NTC, J, JW, KX, CB, splits; };   // one source (x or h) of the reduction
 struct WgPlan {
-  int NTC, J, JW, NB, CBx, CBh, splits_x, splits_h, tiles_x, tiles_y, ntiles, tps_x, tps_h;
+  WgPart part[2];
+  int NB, tiles_x, tiles_y, ntiles;
   size_t off_h, off_db, total_floats;
   int db_rows;
 };
 
 static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_geom* g, WgPlan* pl) {
-  const int taps = ly->k * ly->k;
   if (ly->k != 1 && ly->k != 3 && ly->k != 5) return NINT_E_SHAPE;
-  pl->NTC = (taps * 2 <= 20 && ly->Cxp % 32 == 0 && ly->Chp % 32 == 0) ? 2 : 1;
-  pl->J = taps * pl->NTC;
-  // every wave owns all 4 row tiles (64 gate columns) and a quarter of the (tap, channel-tile) columns
-  pl->JW = pl->J <= 20 ? 5 : 7;
-  if (pl->J > 4 * pl->JW) return NINT_E_SHAPE;
-  const int CW = 16 * pl->NTC;
-  if (ly->Cxp % CW || ly->Chp % CW) return NINT_E_SHAPE;
   pl->NB = 4 * ly->Ch16 / 64;
-  pl->CBx = ly->Cxp / CW;
-  pl->CBh = ly->Chp / CW;
   const int PR = dtype == NINT_BF16 ? 4 : 2;
   pl->tiles_x = g ? nint_cdiv(g->W, 32) : 1;
   pl->tiles_y = g ? nint_cdiv(g->H, PR) : 1;
   pl->ntiles = g ? N * pl->tiles_x * pl->tiles_y : (1 << 30);
   if (n_cu <= 0) n_cu = 256;
-  auto splits_for = [&](int CB) {
+  size_t floats[2];
+  for (int q = 0; q < 2; ++q) {
+    WgPart& w = pl->part[q];
+    const int Cp = q == 0 ? ly->Cxp : ly->Chp;
+    w.KX = (q == 0 && ly->xfold) ? 1 : ly->k;           // folded x source: vertical taps only
+    const int taps = ly->k * w.KX;
+    w.NTC = (taps * 2 <= 20 && Cp % 32 == 0) ? 2 : 1;   // channel tiles per column block
+    w.J = taps * w.NTC;
+    // every wave owns all 4 row tiles (64 gate columns) and a quarter of the (tap, channel-tile) columns
+    w.JW = w.J <= 20 ? 5 : 7;
+    if (w.J > 4 * w.JW) return NINT_E_SHAPE;
+    const int CW = 16 * w.NTC;
+    if (Cp % CW) return NINT_E_SHAPE;
+    w.CB = Cp / CW;
     // two workgroups per CU in flight, but never fewer than 32 pixel tiles per split: the
     // accumulator flush (J KiB-tiles per workgroup) must stay small against the K work
-    int s = nint_cdiv(2 * n_cu, pl->NB * CB);
+    int s = nint_cdiv(2 * n_cu, pl->NB * w.CB);
     if (s > pl->ntiles / 32) s = pl->ntiles / 32;
     if (s < 1) s = 1;
-    return s;
-  };
-  pl->splits_x = splits_for(pl->CBx);
-  pl->splits_h = splits_for(pl->CBh);
-  pl->tps_x = nint_cdiv(pl->ntiles, pl->splits_x);
-  pl->tps_h = nint_cdiv(pl->ntiles, pl->splits_h);
-  // re-derive the split count so that no split is empty
-  pl->splits_x = nint_cdiv(pl->ntiles, pl->tps_x);
-  pl->splits_h = nint_cdiv(pl->ntiles, pl->tps_h);
-  const size_t fx = (size_t)pl->splits_x * pl->NB * pl->CBx * pl->J * 1024;
-  const size_t fh = (size_t)pl->splits_h * pl->NB * pl->CBh * pl->J * 1024;
+    // re-derive the split count so that no split is empty
+    w.splits = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
+    floats[q] = (size_t)w.splits * pl->NB * w.CB * w.J * 1024;
+  }
   pl->db_rows = 64;
-  pl->off_h = fx;
-  pl->off_db = fx + fh;
-  pl->total_floats = fx + fh + (size_t)pl->db_rows * 4 * ly->Ch16;
+  pl->off_h = floats[0];
+  pl->off_db = floats[0] + floats[1];
+  pl->total_floats = floats[0] + floats[1] + (size_t)pl->db_rows * 4 * ly->Ch16;
   return NINT_OK;
 }
 
@@ -399,7 +405,7 @@ extern "C" size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, in
   return pl.total_floats * sizeof(float);
 }
 
-template <int DT, int JW, int KS, int NTCT>
+template <int DT, int JW, int KS, int NTCT, int KX>
 static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   typedef WgTile<DT> TT;
   const int p = a.p;
@@ -407,8 +413,8 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   const int b_bytes = nint_round_up((TT::PR + 2 * p) * (32 + 2 * p) * TT::rb(a.NTC), 1024);   // whole 1-KiB DMA pieces
   const size_t lds = 2 * (size_t)(a_bytes + b_bytes);
   if (lds > 160 * 1024) return NINT_E_LDS;
-  if (a.k != KS || a.NTC != NTCT) return NINT_E_ARG;
-  auto kern = wgrad_kernel<DT, JW, 1, KS, NTCT>;
+  if (a.k != KS || a.NTC != NTCT || a.J != KS * KX * NTCT) return NINT_E_ARG;
+  auto kern = wgrad_kernel<DT, JW, 1, KS, NTCT, KX>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(splits, nblk), dim3(256), lds, st, a);
@@ -416,16 +422,21 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   return NINT_OK;
 }
 
-// instantiated (kernel size, channel tiles, columns per wave) combinations
+// instantiated (kernel size, channel tiles, columns per wave, horizontal taps) combinations
 template <int DT>
-static int dispatch_wgrad(WgradArgs& a, const WgPlan& pl, int splits, int nblk, hipStream_t st) {
-  const int key = a.k * 1000 + a.NTC * 100 + pl.JW;
+static int dispatch_wgrad(WgradArgs& a, const WgPart& w, int nblk, hipStream_t st) {
+  const int key = a.k * 1000 + w.NTC * 100 + w.JW * 10 + w.KX;
   switch (key) {
-    case 5 * 1000 + 1 * 100 + 7: return launch_wgrad<DT, 7, 5, 1>(a, splits, nblk, st);
-    case 3 * 1000 + 2 * 100 + 5: return launch_wgrad<DT, 5, 3, 2>(a, splits, nblk, st);
-    case 3 * 1000 + 1 * 100 + 5: return launch_wgrad<DT, 5, 3, 1>(a, splits, nblk, st);
-    case 1 * 1000 + 2 * 100 + 5: return launch_wgrad<DT, 5, 1, 2>(a, splits, nblk, st);
-    case 1 * 1000 + 1 * 100 + 5: return launch_wgrad<DT, 5, 1, 1>(a, splits, nblk, st);
+    case 5 * 1000 + 1 * 100 + 7 * 10 + 5: return launch_wgrad<DT, 7, 5, 1, 5>(a, w.splits, nblk, st);
+    case 3 * 1000 + 2 * 100 + 5 * 10 + 3: return launch_wgrad<DT, 5, 3, 2, 3>(a, w.splits, nblk, st);
+    case 3 * 1000 + 1 * 100 + 5 * 10 + 3: return launch_wgrad<DT, 5, 3, 1, 3>(a, w.splits, nblk, st);
+    case 1 * 1000 + 2 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 1, 2, 1>(a, w.splits, nblk, st);
+    case 1 * 1000 + 1 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 1, 1, 1>(a, w.splits, nblk, st);
+    // horizontally folded x source (thin first-layer inputs)
+    case 5 * 1000 + 2 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 5, 2, 1>(a, w.splits, nblk, st);
+    case 5 * 1000 + 1 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 5, 1, 1>(a, w.splits, nblk, st);
+    case 3 * 1000 + 2 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 3, 2, 1>(a, w.splits, nblk, st);
+    case 3 * 1000 + 1 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 3, 1, 1>(a, w.splits, nblk, st);
     default: return NINT_E_SHAPE;
   }
 }
@@ -446,6 +457,7 @@ int nint_internal_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype
   const int Gc = 4 * ly->Ch16;
   hipStream_t st = (hipStream_t)stream;
   for (int part = 0; part < 2; ++part) {
+    const WgPart& w = pl.part[part];
     WgradArgs a = {};
     a.dG_pix_stride = Gc * es;
     a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
@@ -456,27 +468,25 @@ int nint_internal_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype
     a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
     a.src = (const char*)(part == 0 ? x_slab : h_slab) + (size_t)skip * a.src_img_stride;
     a.partial = partial + (part == 0 ? 0 : pl.off_h);
-    a.CB = part == 0 ? pl.CBx : pl.CBh;
-    a.NTC = pl.NTC; a.J = pl.J;
-    a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * ly->k;
+    a.CB = w.CB;
+    a.NTC = w.NTC; a.J = w.J;
+    a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * w.KX;
     a.P = g->P; a.Wh = g->Wh;
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
     a.ntiles = (N - skip) * pl.tiles_x * pl.tiles_y;  // empty splits flush zeros
-    const int splits = part == 0 ? pl.splits_x : pl.splits_h;
-    a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, splits) : 1;   // spread what is there evenly over the planned splits
+    a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
     const int nblk = pl.NB * a.CB;
-    rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, pl, splits, nblk, st) : dispatch_wgrad<NINT_F32>(a, pl, splits, nblk, st);
+    rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);
     if (rc != NINT_OK) return rc;
   }
   // fold the split-K slabs into dW, and the bias gradient from the fused pointwise partial rows (or a column-sum pass over dG)
   for (int part = 0; part < 2; ++part) {
-    const int CB = part == 0 ? pl.CBx : pl.CBh;
-    const size_t slab = (size_t)pl.NB * CB * pl.J * 1024;
-    const int splits = part == 0 ? pl.splits_x : pl.splits_h;
+    const WgPart& w = pl.part[part];
+    const size_t slab = (size_t)pl.NB * w.CB * w.J * 1024;
     // few large slabs: 4 waves share the splits; many small slabs: 16 waves
-    const int threads = splits >= 64 ? 1024 : 256;
+    const int threads = w.splits >= 64 ? 1024 : 256;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(slab / 64)), dim3(threads), 0, st, partial + (part == 0 ? 0 : pl.off_h), dW,
-                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, CB, pl.NTC, splits, part);
+                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, w.CB, w.NTC, w.J, w.splits, part, ly->xfold);
     NINT_LAUNCH_CHECK();
   }
   {

@@ -55,7 +55,8 @@ class SlabBatch:
         H, W = ds.grid
         t0 = (C.c_int * B)(*[int(t) for t in self.t0])
         check(_lib.load().nint_preproc_fuse_pad_slab(ptrs, lev, len(lev), ptr(dv["mean"]), ptr(dv["std"]), t0, B,
-                                                     ptr(ws.xs), ws.Cxp0, T, H, W, C.byref(ws.g), ds.mode, eng.dt,
+                                                     ptr(ws.xs), ws.Cxp0, eng.cfgs[0].k if eng.cfgs[0].xfold else 0, T, H, W,
+                                                     C.byref(ws.g), ds.mode, eng.dt,
                                                      stream_ptr()), "nint_preproc_fuse_pad_slab")
 
 

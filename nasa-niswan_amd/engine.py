@@ -15,6 +15,10 @@ from ._lib import NINT_BF16, NINT_F32, NintGeom, NintLayer, NintSeq, check, ptr,
 # 0: the library picks the gate / dgrad pixel-tile height per launch shape; 4 or 8 forces it for every layer of
 # engines built afterwards (nint_layer.tile_rows) -- how the tests run both heights on every shape
 FORCE_TILE_ROWS = 0
+# Thin first-layer inputs (the reference's Conv2d(5+64 -> 256, k=5), model.py:207-211) are fed HORIZONTALLY FOLDED
+# when that lowers the number of MFMA K-steps (nint_xfold_pays): 5 x-steps instead of 25.  False keeps the plain
+# channel-padded layout for engines built afterwards (tests run both).
+XFOLD = True
 
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
 
@@ -36,9 +40,10 @@ class LayerCfg:
     Cx: int
     Ch: int
     k: int
+    xfold: bool = False      # x source horizontally folded (thin first-layer inputs; set by SeqEngine, nint_layer.xfold)
 
     def padded(self, kc: int) -> Tuple[int, int, int]:
-        return _rup(self.Cx, kc), _rup(self.Ch, 16), _rup(self.Ch, kc)
+        return _rup(self.k * self.Cx if self.xfold else self.Cx, kc), _rup(self.Ch, 16), _rup(self.Ch, kc)
 
 
 class Workspace:
@@ -57,7 +62,7 @@ class Workspace:
         halo_px, comp_px = g.Hh * g.Wh, H * W
         u8 = dict(dtype=torch.uint8, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        Cxp0 = _rup(eng.cfgs[0].Cx, kc)
+        Cxp0 = eng.cfgs[0].padded(kc)[0]
         self.xs = torch.zeros(T * B * halo_px * Cxp0 * es, **u8)
         self.h, self.c, self.gates, self.dG, self.dh, self.dc, self.dbp = [], [], [], [], [], [], []
         for cfg in eng.cfgs:
@@ -110,10 +115,11 @@ class SeqEngine:
         if self.device.type != "cuda":
             raise _lib.NintError("the ConvLSTM hot path runs on the MI355X only (device must be cuda); "
                                  "there is no CPU fallback")
-        self.cfgs = list(cfgs)
         self.dt = dtype_code(dtype)
         self.es = 2 if self.dt == NINT_BF16 else 4
         self.kc = self.lib.nint_kc(self.dt)
+        self.cfgs = [LayerCfg(c.Cx, c.Ch, c.k, bool(l == 0 and XFOLD and self.lib.nint_xfold_pays(c.Cx, c.k, self.dt)))
+                     for l, c in enumerate(cfgs)]
         self.P = max(c.k // 2 for c in cfgs)
         for c in cfgs:
             if c.k % 2 == 0:
@@ -126,13 +132,14 @@ class SeqEngine:
         self.Wf, self.Wd, self.bias_p, self.layers = [], [], [], []
         wg_bytes = 0
         for cfg in self.cfgs:
-            nbytes = self.lib.nint_packed_weight_bytes(cfg.Cx, cfg.Ch, cfg.k, self.dt, 0)
+            nbytes = self.lib.nint_packed_weight_bytes(cfg.Cx, cfg.Ch, cfg.k, self.dt, int(cfg.xfold))
             Cxp, Ch16, Chp = cfg.padded(self.kc)
             self.Wf.append(torch.zeros(nbytes, **u8))
             self.Wd.append(torch.zeros(nbytes, **u8))
             self.bias_p.append(torch.zeros(4 * Ch16, dtype=torch.float32, device=self.device))
             ly = NintLayer()
             ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k = cfg.Cx, Cxp, cfg.Ch, Ch16, Chp, cfg.k
+            ly.xfold = int(cfg.xfold)
             ly.Wf, ly.Wd, ly.bias_p = self.Wf[-1].data_ptr(), self.Wd[-1].data_ptr(), self.bias_p[-1].data_ptr()
             self.layers.append(ly)
             ly.tile_rows = FORCE_TILE_ROWS
@@ -165,7 +172,7 @@ class SeqEngine:
                 if b.dtype != torch.float32 or not b.is_contiguous():
                     b = b.float().contiguous()
             check(self.lib.nint_pack_weights(ptr(W), ptr(b), ptr(self.Wf[l]), ptr(self.Wd[l]), ptr(self.bias_p[l]),
-                                             cfg.Cx, cfg.Ch, cfg.k, self.dt, st), "nint_pack_weights")
+                                             cfg.Cx, cfg.Ch, cfg.k, int(cfg.xfold), self.dt, st), "nint_pack_weights")
 
     @staticmethod
     def untrainable_layers(cfgs: Sequence[LayerCfg], dtype, n_cu: int = 256) -> List[str]:
@@ -178,7 +185,7 @@ class SeqEngine:
         bad = []
         for l, cfg in enumerate(cfgs):
             ly = NintLayer()
-            ly.Cx, ly.Ch, ly.k = cfg.Cx, cfg.Ch, cfg.k
+            ly.Cx, ly.Ch, ly.k, ly.xfold = cfg.Cx, cfg.Ch, cfg.k, int(cfg.xfold)
             ly.Cxp, ly.Ch16, ly.Chp = cfg.padded(kc)
             if lib.nint_wgrad_workspace_bytes(C.byref(ly), dt, n_cu) == 0:
                 bad.append(f"layer {l} (Cin={cfg.Cx}, Ch={cfg.Ch}, k={cfg.k})")
@@ -215,14 +222,7 @@ class SeqEngine:
         assert (B, T, H, W) == (ws.B, ws.T, ws.H, ws.W) and Cc == self.cfgs[0].Cx
         st = stream_ptr()
         g = C.byref(ws.g)
-        if hasattr(x, "fill_slab"):
-            # an un-materialised batch (dataset.SlabBatch): the preproc kernel writes the input slab directly
-            x.fill_slab(self, ws)
-        else:
-            x = x.detach()
-            if x.dtype != torch.float32 or not x.is_contiguous():
-                x = x.float().contiguous()
-            check(self.lib.nint_pack_btchw(ptr(x), ptr(ws.xs), B, T, Cc, ws.Cxp0, g, self.dt, st), "nint_pack_btchw")
+        self.pack_input(ws, x)
         if h0 is not None:
             for l, cfg in enumerate(self.cfgs):
                 Chp = cfg.padded(self.kc)[2]
@@ -233,6 +233,23 @@ class SeqEngine:
                 check(self.lib.nint_pack_compact(ptr(cc), C.c_void_p(ws.c_view(self, l, 0)), B, cfg.Ch, Chp, H, W, NINT_F32, st),
                       "pack c0")
         check(self.lib.nint_seq_fwd(C.byref(ws.seq), st), "nint_seq_fwd")
+
+    def pack_input(self, ws: Workspace, x):
+        """Fill the input slab ws.xs (image t*B+b, channels-last ET, folded for thin inputs) from x: a (B,T,C,H,W)
+        f32 tensor (nint_pack_btchw[_xfold]) or a dataset.SlabBatch (the preproc kernel writes the slab directly)."""
+        B, T, Cc, H, W = x.shape
+        if hasattr(x, "fill_slab"):
+            x.fill_slab(self, ws)
+            return
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        st, g = stream_ptr(), C.byref(ws.g)
+        if self.cfgs[0].xfold:
+            check(self.lib.nint_pack_btchw_xfold(ptr(x), ptr(ws.xs), B, T, Cc, self.cfgs[0].k, ws.Cxp0, g, self.dt, st),
+                  "nint_pack_btchw_xfold")
+        else:
+            check(self.lib.nint_pack_btchw(ptr(x), ptr(ws.xs), B, T, Cc, ws.Cxp0, g, self.dt, st), "nint_pack_btchw")
 
     def h_last(self, ws: Workspace, l: int, slot: Optional[int] = None) -> torch.Tensor:
         cfg = self.cfgs[l]
@@ -319,8 +336,12 @@ class SeqEngine:
             # compact [T*B][H][W][Cxp0] -> (B,T,C,H,W)
             C0 = self.cfgs[0].Cx
             tb = torch.empty(ws.T * ws.B, C0, ws.H, ws.W, dtype=torch.float32, device=self.device)
-            check(self.lib.nint_unpack_compact(ptr(dx), ptr(tb), ws.T * ws.B, C0, ws.Cxp0, ws.H, ws.W, self.dt, stream_ptr()),
-                  "unpack dx")
+            if self.cfgs[0].xfold:     # gradient of the folded input -> gradient of the input
+                check(self.lib.nint_unfold_dx(ptr(dx), ptr(tb), ws.T * ws.B, C0, self.cfgs[0].k, ws.Cxp0, ws.H, ws.W, self.dt,
+                                              stream_ptr()), "nint_unfold_dx")
+            else:
+                check(self.lib.nint_unpack_compact(ptr(dx), ptr(tb), ws.T * ws.B, C0, ws.Cxp0, ws.H, ws.W, self.dt, stream_ptr()),
+                      "unpack dx")
             dx_out = tb.view(ws.T, ws.B, C0, ws.H, ws.W).transpose(0, 1).contiguous()
         return dWs, dbs, dx_out
 

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in nint.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.nint_version() == 104
+    assert lib.nint_version() == 105
     assert lib.nint_kc(0) == 16 and lib.nint_kc(1) == 32
     assert lib.nint_error_string(-2).decode().startswith("nint:")
 
@@ -56,6 +56,9 @@ def test_geometry_and_workspace_queries_are_host_only():
     assert lib.nint_geom_make(C.byref(g), 0, 154, 2) == -1
     # packed weight image of the reference's first layer in bf16: (Cxp+Chp)*4*Ch16*k*k*2 bytes
     assert lib.nint_packed_weight_bytes(5, 64, 5, 1, 0) == (32 + 64) * 256 * 25 * 2
+    # horizontal folding of thin first-layer inputs: pays when it lowers the x K-steps (reference layer 0: 25 -> 5)
+    assert lib.nint_xfold_pays(5, 5, 1) == 1 and lib.nint_xfold_pays(5, 5, 0) == 1 and lib.nint_xfold_pays(4, 3, 0) == 1
+    assert lib.nint_xfold_pays(62, 5, 1) == 0 and lib.nint_xfold_pays(5, 1, 1) == 0 and lib.nint_xfold_pays(64, 3, 1) == 0
     ly = _lib.NintLayer()
     ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k = 5, 32, 64, 64, 64, 5
     assert lib.nint_wgrad_workspace_bytes(C.byref(ly), 1, 256) > 0

@@ -32,6 +32,43 @@ def geom(lib, H, W, Pd):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
+def test_xfold_pack_and_its_adjoint(lib, dt):
+    """nint_layer.xfold layout: slab channel kx*C + c of pixel x holds input channel c of pixel x + kx - k//2, zero
+    outside the image (the convolution's own zero padding); nint_unfold_dx is the adjoint of that fold (what the
+    input gradient of a folded first layer needs)."""
+    B, T, Cc, H, W, Pd, k = 2, 2, 5, 9, 37, 2, 5
+    g = geom(lib, H, W, Pd)
+    kc = lib.nint_kc(dt)
+    Cp = (k * Cc + kc - 1) // kc * kc
+    es = 2 if dt else 4
+    x = torch.randn(B, T, Cc, H, W, device="cuda")
+    slab = torch.zeros(T * B * g.Hh * g.Wh * Cp * es, dtype=torch.uint8, device="cuda")
+    assert lib.nint_pack_btchw_xfold(P(x), P(slab), B, T, Cc, k, Cp, C.byref(g), dt, None) == 0
+    torch.cuda.synchronize()
+    view = slab.view(torch.bfloat16 if dt else torch.float32).view(T * B, g.Hh, g.Wh, Cp).float()
+    ref = x.transpose(0, 1).reshape(T * B, Cc, H, W)
+    if dt:
+        ref = ref.to(torch.bfloat16).float()
+    pad = torch.nn.functional.pad(ref, (k // 2, k // 2))                      # zeros left / right
+    want = torch.cat([pad[:, :, :, kx:kx + W] for kx in range(k)], dim=1)     # (N, k*C, H, W), channel kx*C + c
+    assert torch.equal(view[:, Pd:Pd + H, Pd:Pd + W, :k * Cc], want.permute(0, 2, 3, 1))
+    assert float(view[..., k * Cc:].abs().max()) == 0
+    assert float(view[:, :Pd].abs().max()) == 0 and float(view[:, :, Pd + W:].abs().max()) == 0
+    # adjoint: <fold(x), G> == <x, unfold(G)> for a random G in the folded compact layout [N][H][W][Cp] (f32)
+    N = T * B
+    G = torch.randn(N, H, W, Cp, device="cuda")
+    dx = torch.empty(N, Cc, H, W, device="cuda")
+    assert lib.nint_unfold_dx(P(G), P(dx), N, Cc, k, Cp, H, W, 0, None) == 0
+    torch.cuda.synchronize()
+    xr = x.transpose(0, 1).reshape(N, Cc, H, W)
+    padx = torch.nn.functional.pad(xr, (k // 2, k // 2))
+    fold = torch.cat([padx[:, :, :, kx:kx + W] for kx in range(k)], dim=1).permute(0, 2, 3, 1)
+    lhs = float((fold.double() * G[..., :k * Cc].double()).sum())
+    rhs = float((xr.double() * dx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * (abs(lhs) + 1.0)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
 def test_pack_unpack_roundtrip_and_zero_halo(lib, dt):
     B, T, Cc, H, W, Pd = 2, 3, 5, 9, 37, 2
     g = geom(lib, H, W, Pd)

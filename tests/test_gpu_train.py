@@ -137,50 +137,61 @@ def test_dataset_device_batch_matches_oracle_preproc(pkg):
         assert torch.equal(Xi, X[1]) and yi.shape == ((90, 144) if levels == 1 else (levels, 90, 144))
 
 
+@pytest.mark.parametrize("fold", [True, False], ids=["xfold", "plain"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_slab_batch_is_bit_identical_to_preproc_then_pack(pkg, dtype):
+def test_slab_batch_is_bit_identical_to_preproc_then_pack(pkg, dtype, fold):
     """a-6 straight into the slab: `nint_preproc_fuse_pad_slab` (one launch per batch, no f32 intermediate) must
     write exactly the bytes that the oracle's preproc followed by the pack kernel's rounding produces: compared
-    (1) byte for byte with device_batch -> nint_pack_btchw on the same windows, whose f32 values are themselves
-    checked against preproc_oracle above, and (2) directly against preproc_oracle rounded to the slab type."""
-    import ctypes as C
-    from nasa_niswan_amd import _lib
+    (1) byte for byte with device_batch -> nint_pack_btchw[_xfold] on the same windows, whose f32 values are themselves
+    checked against preproc_oracle above, and (2) directly against preproc_oracle rounded to the slab type.
+    With `fold` the thin 5-channel input is written HORIZONTALLY FOLDED (nint_layer.xfold: slab channel kx*C + c of
+    pixel x = channel c of pixel x + kx - 1, zero outside the padded grid); the 62-channel input never folds."""
+    from nasa_niswan_amd import engine
     from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
     from nasa_niswan_amd.engine import LayerCfg, SeqEngine
     from oracle import preproc_oracle as PO
-    for levels, mode, idx in ((1, "reference", [3, 0, 9]), (20, "reflect", [1, 5])):
-        Cin = 3 * levels + 2
-        ds = SyntheticE33OMA_CRNN("train", padding=(100, 154), in_channels=Cin, sequence_length=3, levels=levels,
-                                  n_steps=24, pad_mode=mode, device="cuda")
-        eng = SeqEngine([LayerCfg(Cin, 16, 3)], dtype, "cuda")
-        B = len(idx)
-        ws_a = eng.acquire(B, 3, 100, 154, False, False)
-        ws_b = eng.acquire(B, 3, 100, 154, False, False)
-        assert ws_a is not ws_b
-        sb, y1 = ds.slab_batch(idx)
-        sb.fill_slab(eng, ws_a)
-        X, y2 = ds.device_batch(idx)
-        _lib.check(_lib.load().nint_pack_btchw(_lib.ptr(X), _lib.ptr(ws_b.xs), B, 3, Cin, ws_b.Cxp0, C.byref(ws_b.g), eng.dt,
-                                               _lib.stream_ptr()), "pack")
-        torch.cuda.synchronize()
-        assert torch.equal(ws_a.xs, ws_b.xs) and torch.equal(y1, y2), (levels, mode)
-        # directly against the oracle: image t*B+b, interior [P, P+100) x [P, P+154), channels-last
-        g, Cp = ws_a.g, ws_a.Cxp0
-        et = torch.float32 if dtype == "f32" else torch.bfloat16
-        slab = ws_a.xs.view(et).view(3 * B, g.Hh, g.Wh, Cp)[:, g.P:g.P + 100, g.P:g.P + 154].float().cpu()
-        assert float(ws_a.xs.view(et).view(3 * B, g.Hh, g.Wh, Cp)[:, :, :, Cin:].abs().max()) == 0.0      # channel padding zero
-        for b, i in enumerate(idx):
-            fields, _ = ds.window(i)
-            args = [f if (levels > 1 or f.ndim == 3) else f[:, 0] for f in fields]
-            ref = torch.from_numpy(PO.preproc_sample(*args, ds.X_mean, ds.X_std, (100, 154), mode))   # (T,C,Hp,Wp)
-            want = ref.to(et).float().permute(0, 2, 3, 1)
-            got = slab[b::B][:, :, :, :Cin]
-            if dtype == "f32":
-                np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
-            else:   # the f32 value may differ from numpy's in the last bit before rounding: <= 1 bf16 ulp, and rarely
-                d = (got - want).abs()
-                assert float((d > 0).float().mean()) < 1e-3 and float((d / (want.abs() + 1e-6)).max()) <= 2 ** -7
-        eng.release(ws_a); eng.release(ws_b)
+    engine.XFOLD = fold
+    try:
+        for levels, mode, idx in ((1, "reference", [3, 0, 9]), (20, "reflect", [1, 5])):
+            Cin, k = 3 * levels + 2, 3
+            ds = SyntheticE33OMA_CRNN("train", padding=(100, 154), in_channels=Cin, sequence_length=3, levels=levels,
+                                      n_steps=24, pad_mode=mode, device="cuda")
+            eng = SeqEngine([LayerCfg(Cin, 16, k)], dtype, "cuda")
+            folded = eng.cfgs[0].xfold
+            assert folded == (fold and levels == 1)
+            B = len(idx)
+            ws_a = eng.acquire(B, 3, 100, 154, False, False)
+            ws_b = eng.acquire(B, 3, 100, 154, False, False)
+            assert ws_a is not ws_b
+            sb, y1 = ds.slab_batch(idx)
+            eng.pack_input(ws_a, sb)
+            X, y2 = ds.device_batch(idx)
+            eng.pack_input(ws_b, X)
+            torch.cuda.synchronize()
+            assert torch.equal(ws_a.xs, ws_b.xs) and torch.equal(y1, y2), (levels, mode)
+            # directly against the oracle: image t*B+b, interior [P, P+100) x [P, P+154), channels-last
+            g, Cp = ws_a.g, ws_a.Cxp0
+            et = torch.float32 if dtype == "f32" else torch.bfloat16
+            full = ws_a.xs.view(et).view(3 * B, g.Hh, g.Wh, Cp)
+            slab = full[:, g.P:g.P + 100, g.P:g.P + 154].float().cpu()
+            nch = Cin * k if folded else Cin
+            assert float(full[:, :, :, nch:].abs().max()) == 0.0                     # channel padding zero
+            for b, i in enumerate(idx):
+                fields, _ = ds.window(i)
+                ref = torch.from_numpy(PO.preproc_sample(*fields, ds.X_mean, ds.X_std, (100, 154), mode))   # (T,C,Hp,Wp)
+                want = ref.to(et).float().permute(0, 2, 3, 1)                        # (T,Hp,Wp,C)
+                if folded:     # channel kx*C + c of pixel x = channel c of pixel x + kx - k//2, zero outside
+                    pad = torch.nn.functional.pad(want, (0, 0, k // 2, k // 2))
+                    want = torch.cat([pad[:, :, kx:kx + 154] for kx in range(k)], dim=3)
+                got = slab[b::B][:, :, :, :nch]
+                if dtype == "f32":
+                    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+                else:   # the f32 value may differ from numpy's in the last bit before rounding: <= 1 bf16 ulp, and rarely
+                    d = (got - want).abs()
+                    assert float((d > 0).float().mean()) < 1e-3 and float((d / (want.abs() + 1e-6)).max()) <= 2 ** -7
+            eng.release(ws_a); eng.release(ws_b)
+    finally:
+        engine.XFOLD = True
 
 
 def test_train_py_end_to_end(pkg, tmp_path, monkeypatch):
@@ -328,7 +339,26 @@ def test_both_tile_heights_keep_parity_on_every_shape(pkg, rows):
         for name in ("ragged-grid-odd-channels", "k1-and-k3", "wide-hidden-48"):
             for dtype in ("f32", "bf16"):
                 check(run_case(pkg, *CASES[name], dtype), dtype)
-        check(run_case(pkg, 5, [64, 32, 16], [5, 3, 3], 1, 2, 2, 20, 36, "f32"), "f32")      # the reference stack
+        check(run_case(pkg, 5, [64, 32, 16], [5, 3, 3], 1, 2, 2, 20, 36, "f32"), "f32")      # the reference stack (folded x)
         check(run_case(pkg, 62, [64, 32, 16], [5, 3, 3], 20, 1, 2, 100, 154, "bf16"), "bf16")  # bench geometry, T=2
     finally:
         engine.FORCE_TILE_ROWS = 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_thin_inputs_plain_layout_keeps_parity(pkg, dtype):
+    """Thin first-layer inputs are fed horizontally folded by default (nint_layer.xfold, covered by every small-channel
+    case of the suite and the reference-size goldens); the plain channel-padded layout stays available
+    (engine.XFOLD = False) and must give the same results: forward, all weight gradients and the input gradient."""
+    from nasa_niswan_amd import engine
+    from test_gpu_shapes import check, run_case
+    for fold in (False, True):
+        engine.XFOLD = fold
+        try:
+            net = pkg.ConvLSTM(5, [16], [5], 1, compute_dtype=dtype).cuda()
+            assert net._engine(torch.device("cuda", 0)).cfgs[0].xfold == fold
+            check(run_case(pkg, 5, [64, 32, 16], [5, 3, 3], 1, 2, 3, 20, 36, dtype), dtype)   # reference stack, 5 inputs
+            check(run_case(pkg, 4, [8], [3], 1, 2, 4, 32, 32, dtype), dtype)                  # BASELINE configs[0]
+            check(run_case(pkg, 7, [24, 16], [3, 5], 1, 3, 2, 11, 19, dtype), dtype)          # ragged grid, odd channels
+        finally:
+            engine.XFOLD = True

@@ -51,7 +51,7 @@ def main():
     _engine.FORCE_TILE_ROWS = args.tile_rows
     eng = SeqEngine(cfgs, args.dtype, "cuda")
     for ly in eng.layers:
-        ly.reserved1 = args.dbg
+        ly.tile_rows = args.tile_rows | (args.dbg << 8)
     B, T, H, W = args.batch, args.T, args.H, args.W
     ws = eng.acquire(B, T, H, W, True, False)
     ws_w = [torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * (0.0 if args.zeros else 0.05) for c in cfgs]
