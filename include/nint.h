@@ -94,7 +94,8 @@ typedef struct nint_seq {
   float* dW[NINT_MAX_LAYERS];          /* f32 OIHW (4Ch, Cx+Ch, k, k) gradient, overwritten */
   float* db[NINT_MAX_LAYERS];          /* f32 (4Ch) gradient, overwritten */
   float* db_partial[NINT_MAX_LAYERS];  /* f32 [T][NINT_DB_ROWS][4*Ch16] bias-gradient partial rows (may be NULL) */
-  float* wg_partial;                   /* f32 split-K slabs for wgrad (size from nint_wgrad_workspace_bytes) */
+  float* wg_partial;                   /* f32 split-K slabs for wgrad: the SUM over the layers of nint_wgrad_workspace_bytes
+                                        * (each rounded up to 256 bytes) -- the layers' slabs sit side by side */
   size_t wg_partial_bytes;
 } nint_seq;
 
@@ -140,6 +141,11 @@ size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int xfold);
  * -> Wf, Wd (fragment order, ET) and bias_p.  Must be re-run after every optimiser step. */
 int nint_pack_weights(const float* W, const float* bias, void* Wf, void* Wd, float* bias_p,
                       int Cx, int Ch, int k, int xfold, int dtype, void* stream);
+
+/* the same for every layer of a model in ONE launch: W[l] / bias[l] (host arrays of device pointers; bias[l] may be
+ * NULL) into layers[l].Wf / .Wd / .bias_p */
+int nint_pack_weights_layers(const float* const* W /*host*/, const float* const* bias /*host*/,
+                             const struct nint_layer* layers /*host*/, int L, int dtype, void* stream);
 
 /* ---- the hot path: one cell step ----------------------------------------------------------- */
 /* ConvLSTMCell.forward (model.py:216-231): gates = conv(cat[x,h]) ; sigmoid/tanh ; c,h update,
@@ -190,15 +196,23 @@ int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp, int O, con
 /* ---- loss (train.py:102,105) ------------------------------------------------------------------ */
 /* pred (N,O,H,W) f32, y (N,O,Hc,Wc) f32; crop window [oy,oy+Hc) x [ox,ox+Wc).
  * loss_out: NINT_LOSS_SCRATCH_FLOATS floats, 8-byte aligned; [0] = mean((y-p)^2) + mean(|y-p|), the
- * rest is reduction scratch; dpred (N,O,H,W) = d loss / d pred (0 outside the
+ * rest is reduction scratch (4 doubles per workgroup of the partial-sum launch, up to 1024 workgroups); dpred (N,O,H,W) = d loss / d pred (0 outside the
  * crop), may be NULL; stats (NINT_LOSS_STATS doubles, accumulated, caller zeroes): [0..4] pooled sums
  * sum (y-p)^2, sum |y-p|, sum y, sum y^2, count; [5..7] the reference's per-batch statistics: sum over calls
  * of the loss, sum over calls of sklearn-style r2_score(y, pred) of that call, number of calls -- the
  * device-side accumulators replacing loss.item() / r2_score(...cpu()) of train.py:113-117, utils.py:73-75. */
-#define NINT_LOSS_SCRATCH_FLOATS 2050
+#define NINT_LOSS_SCRATCH_FLOATS 8194
 #define NINT_LOSS_STATS 8
 int nint_loss_mse_l1_crop(const float* pred, const float* y, float* dpred, float* loss_out, double* stats,
                           int N, int O, int H, int W, int oy, int ox, int Hc, int Wc, void* stream);
+
+/* Training fast path: head forward + crop + loss + d loss/d pred + head backward-data in ONE pass over the pixels
+ * (train.py:96-109 around model.py:274); the same arithmetic in the same order as nint_head_fwd ->
+ * nint_loss_mse_l1_crop -> nint_head_bwd(dh).  pred is not materialised; dpred (N,O,H,W) is written for
+ * nint_head_bwd(dh = NULL) to form dw / db.  Chp <= 64, else NINT_E_SHAPE (use the three separate entries). */
+int nint_head_loss_fused(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w, const float* b,
+                         const float* y, float* dpred, void* dh, float* loss_out, double* stats, const nint_geom* g,
+                         int oy, int ox, int Hc, int Wc, int dtype, void* stream);
 
 /* ---- optimiser (train.py:71,110) ---------------------------------------------------------------- */
 /* torch.optim.Adam (eps 1e-8, no weight decay / amsgrad) on one flat f32 buffer.

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("NINT_LIB", os.path.join(HERE, "libnint_hip.so"))   # 
 
 NINT_F32, NINT_BF16 = 0, 1
 NINT_MAX_LAYERS = 8
-NINT_LOSS_SCRATCH_FLOATS = 2050
+NINT_LOSS_SCRATCH_FLOATS = 8194
 NINT_LOSS_STATS = 8
 NINT_DB_ROWS = 1024
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "nint_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "nint_xfold_pays": (_I, [_I, _I, _I]),
     "nint_pack_weights": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, _I, vp]),
+    "nint_pack_weights_layers": (_I, [C.POINTER(vp), C.POINTER(vp), C.POINTER(NintLayer), _I, _I, vp]),
     "nint_pack_btchw_xfold": (_I, [vp, vp, _I, _I, _I, _I, _I, _PG, _I, vp]),
     "nint_unfold_dx": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, _I, vp]),
     "nint_cell_fwd": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "nint_head_fwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, _PG, _I, vp]),
     "nint_head_bwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, vp, vp, _PG, _I, vp, _SZ, vp]),
     "nint_loss_mse_l1_crop": (_I, [vp, vp, vp, vp, vp, _I, _I, _I, _I, _I, _I, _I, _I, vp]),
+    "nint_head_loss_fused": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, _PG, _I, _I, _I, _I, _I, vp]),
     "nint_adam_flat": (_I, [vp, vp, vp, vp, _SZ, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, vp]),
     "nint_preproc_fuse_pad": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, vp, _I, _I, _I, _I, _I, _I, vp]),
     "nint_preproc_fuse_pad_batch": (_I, [C.POINTER(vp), C.POINTER(_I), _I, vp, vp, C.POINTER(_I), _I, vp, _I, _I, _I, _I, _I, _I, vp]),

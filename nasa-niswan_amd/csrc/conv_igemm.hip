@@ -60,8 +60,18 @@ extern "C" int nint_debug_read_stamps(unsigned long long* host, int n_wgs) {
 #define NINT_STAMP_AT(slot)
 #endif
 
+// Rounds of the K-slice exchange.  Four K-slices of a 4-row tile park 3/4 of the accumulators: in ONE round that
+// buffer (12 KiB per wave, 48 KiB) is the workgroup's whole LDS footprint for the narrow layers and caps them at 3
+// workgroups per CU; in two rounds of half the column tiles it is 24 KiB (under the halo image) and a fourth fits.
+// Measured (same device, rocprofv3): the layer-2 gate kernel -5 %; the dgrad kernels +1 % (their fourth workgroup
+// costs 12 spilled registers), so only the LSTM epilogue takes two rounds.  8-row tiles with four K-slices need four
+// rounds to stay at two workgroups per CU (96 KiB otherwise).
+constexpr int xchg_rounds(int EPI, int WK, int NTW, int MT) {
+  return (EPI == 0 && WK == 4 && MT == 4 && NTW % 2 == 0) ? 2 : ((WK == 4 && MT == 8 && NTW == 4) ? 4 : 1);
+}
+
 template <int DT, int EPI, int WN, int WK, int NTW, int MT>
-__global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) == 2 && DT == NINT_BF16 ? 4 : 3)) void conv_igemm_kernel(ConvArgs a) {
   static_assert(WN * WK == 4, "four waves per workgroup");
   constexpr int BD = MT >= 8 ? BD_WIDE : BD_NARROW;
   static_assert(EPI != EPI_LSTM || NTW % 4 == 0, "LSTM epilogue needs the 4 gate tiles in one wave");
@@ -75,6 +85,15 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wk = wave / WN;
+#ifdef NINT_EXPERIMENT
+  // stagger experiment: the first-dispatched workgroups (one per resident slot) start in 2..4 phase groups, dbg%10 us apart
+  if (a.dbg >= 20 && blockIdx.y == 0) {
+    const int ngrp = a.dbg / 10, us = a.dbg % 10;
+    const int grp = (blockIdx.x >> 8) % ngrp;
+    if ((int)blockIdx.x < 256 * 4)
+      for (int i = 0; i < grp * us; ++i) __builtin_amdgcn_s_sleep(32);     // ~1 us each
+  }
+#endif
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
   // with its own L2, so XCD x takes the CONTIGUOUS tile range x: neighbouring tiles (which share halo
   // pixels) and, at B = 8, whole images then stay inside one L2.  Any bijection is correct.
@@ -124,6 +143,51 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   const unsigned blane = lane * 16;
   const size_t bstep = (size_t)a.NTt * 1024;   // bytes between consecutive K-steps in Bp
 
+  // c_{t-1} of the rows this wave finishes in the epilogue (rows (i + wk*Q) % MT, see the K-slice exchange below).
+  // 4-row tiles (the narrow layers, whose time is all memory latency) fetch it HERE, ahead of the halo fill: the loads
+  // complete under the fill wait instead of stalling the epilogue on an HBM round trip (Q*NTW/4 vectors, 4-8 VGPRs).
+  // 8-row tiles have no registers to spare and fetch it at the top of the epilogue, before the first store: vmcnt
+  // retires in order and counts stores too, so a load issued between the epilogue's stores would make every row wait
+  // for the previous row's stores to be acknowledged (measured: 22 us of epilogue per round).
+  constexpr bool EARLY = MT <= 4;
+  f32x4_t cpv[EPI == EPI_LSTM ? Q : 1][EPI == EPI_LSTM ? NTW / 4 : 1];
+  auto load_cprev = [&]() __attribute__((always_inline)) {
+    if constexpr (EPI == EPI_LSTM) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const int y = y0 + (i + wk * Q) % MT, xq = x0 + (lane & 15);
+        const float* crow = a.c_prev + ((size_t)img * a.H + y) * a.W * a.Chp;     // wave-uniform row base
+#pragma unroll
+        for (int cb = 0; cb < NTW / 4; ++cb) {
+          cpv[i][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (a.c_prev && y < a.H && xq < a.W)
+            cpv[i][cb] = *(const f32x4_t*)(crow + (unsigned)(xq * a.Chp + (nt0 / 4 + cb) * 16 + 4 * (lane >> 4)));
+        }
+      }
+    }
+  };
+  // the read-modify-write operands of the dgrad epilogue (x columns accumulate into the layer below's dh), same rule
+  constexpr bool HOIST = EPI == EPI_DGRAD && Q * NTW <= 16;      // (register budget: the widest tiles keep the load inside the row loop)
+  f32x4_t old[HOIST ? Q : 1][HOIST ? NTW : 1];
+  auto load_old = [&]() __attribute__((always_inline)) {
+    if constexpr (HOIST) {
+      const bool rmw = a.out0 && !a.out0_overwrite;
+      const int c4 = 4 * (lane >> 4), x = x0 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const int y = y0 + (i + wk * Q) % MT;
+        const size_t rowpix = ((size_t)img * a.H + y) * a.W;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int n = (nt0 + j) * 16 + c4;
+          old[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (rmw && n < a.C0p && y < a.H && x < a.W)
+            old[i][j] = load_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + n));
+        }
+      }
+    }
+  };
+  if constexpr (EARLY) { load_cprev(); load_old(); }
   for (int c_begin = 0; c_begin < nchunks; c_begin += a.cpf) {
     const int c_cnt = min(a.cpf, nchunks - c_begin);
     if (c_begin > 0) __syncthreads();          // every wave is done reading the previous image
@@ -305,24 +369,29 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   // lane-linear 1 KiB tiles), barrier, each wave adds the WK-1 foreign partials of its own rows.
   if constexpr (WK > 1) {
     constexpr int FR = MT - Q;                 // foreign rows per wave
+    constexpr int XR = xchg_rounds(EPI, WK, NTW, MT), NTX = NTW / XR;   // column tiles exchanged per round
     __syncthreads();                           // every wave is done reading the A image
-    char* mine = smem + (size_t)((wn * WK + wk) * FR * NTW) * 1024 + lane * 16;
 #pragma unroll
-    for (int ii = Q; ii < MT; ++ii)
+    for (int xr = 0; xr < XR; ++xr) {
+      if (xr > 0) __syncthreads();             // the previous round's partials are consumed
+      char* mine = smem + (size_t)((wn * WK + wk) * FR * NTX) * 1024 + lane * 16;
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) *(f32x4_t*)(mine + ((ii - Q) * NTW + j) * 1024) = acc[ii][j];
-    __syncthreads();
+      for (int ii = Q; ii < MT; ++ii)
 #pragma unroll
-    for (int d = 1; d < WK; ++d) {
-      const int src = (wk + d) % WK;           // slice whose partials are added now
-      // my local row ii is tile row (ii + wk*Q) % MT = local row (ii + (wk-src)*Q) mod MT of `src`
-      const int shift = ((wk - src + WK) % WK) * Q;      // in [Q, MT): always a foreign row there
-      const char* theirs = smem + (size_t)((wn * WK + src) * FR * NTW) * 1024 + lane * 16;
+        for (int j = 0; j < NTX; ++j) *(f32x4_t*)(mine + ((ii - Q) * NTX + j) * 1024) = acc[ii][xr * NTX + j];
+      __syncthreads();
 #pragma unroll
-      for (int ii = 0; ii < Q; ++ii)
+      for (int d = 1; d < WK; ++d) {
+        const int src = (wk + d) % WK;         // slice whose partials are added now
+        // my local row ii is tile row (ii + wk*Q) % MT = local row (ii + (wk-src)*Q) mod MT of `src`
+        const int shift = ((wk - src + WK) % WK) * Q;      // in [Q, MT): always a foreign row there
+        const char* theirs = smem + (size_t)((wn * WK + src) * FR * NTX) * 1024 + lane * 16;
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
-          acc[ii][j] += *(const f32x4_t*)(theirs + ((ii + shift - Q) * NTW + j) * 1024);
+        for (int ii = 0; ii < Q; ++ii)
+#pragma unroll
+          for (int j = 0; j < NTX; ++j)
+            acc[ii][xr * NTX + j] += *(const f32x4_t*)(theirs + ((ii + shift - Q) * NTX + j) * 1024);
+      }
     }
   }
 
@@ -334,20 +403,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
   // c_{t-1} of the rows this wave finishes in the epilogue is fetched up front, before the first store: vmcnt
   // retires in order and counts stores too, so a load issued between the epilogue's stores would make every
   // row wait for the previous row's stores to be acknowledged (measured: 22 us of epilogue per round).
-  f32x4_t cpv[EPI == EPI_LSTM ? Q : 1][EPI == EPI_LSTM ? NTW / 4 : 1];
-  if constexpr (EPI == EPI_LSTM) {
-#pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      const int y = y0 + (i + wk * Q) % MT, xq = x0 + (lane & 15);
-      const float* crow = a.c_prev + ((size_t)img * a.H + y) * a.W * a.Chp;     // wave-uniform row base
-#pragma unroll
-      for (int cb = 0; cb < NTW / 4; ++cb) {
-        cpv[i][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (a.c_prev && y < a.H && xq < a.W)
-          cpv[i][cb] = *(const f32x4_t*)(crow + (unsigned)(xq * a.Chp + (nt0 / 4 + cb) * 16 + 4 * (lane >> 4)));
-      }
-    }
-  }
+  if constexpr (!EARLY) { load_cprev(); load_old(); }
   const int px = lane & 15;
   const int c4 = 4 * (lane >> 4);
   const int x = x0 + px;
@@ -416,20 +472,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : 3) void conv_igemm_kernel(ConvAr
     // issued before the first store (vmcnt retires in order and counts stores: a load between stores would wait
     // for the previous row's stores to be acknowledged).
     const bool rmw = a.out0 && !a.out0_overwrite;
-    constexpr bool HOIST = Q * NTW <= 16;      // (register budget: the widest tiles keep the load inside the row loop)
-    f32x4_t old[HOIST ? Q : 1][HOIST ? NTW : 1];
-#pragma unroll
-    for (int i = 0; i < (HOIST ? Q : 0); ++i) {
-      const int y = y0 + (i + wk * Q) % MT;
-      const size_t rowpix = ((size_t)img * a.H + y) * a.W;
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int n = (nt0 + j) * 16 + c4;
-        old[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (rmw && n < a.C0p && y < a.H && x < a.W)
-          old[i][j] = load_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + n));
-      }
-    }
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
       const int y = y0 + (i + wk * Q) % MT;
@@ -466,7 +508,7 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   a.magic_hwt = (unsigned)(((1ull << 32) + (16 + 2 * a.p) - 1) / (16 + 2 * a.p));
   const int chunk_bytes = 4 * a.nhp_pad * 16;
   const int nchunks = a.nchunk0 + a.nchunk1;
-  const int red_bytes = WK > 1 ? WN * WK * (MT - MT / WK) * NTW * 1024 : 0;   // K-slice exchange buffer
+  const int red_bytes = WK > 1 ? WN * WK * (MT - MT / WK) * (NTW / xchg_rounds(EPI, WK, NTW, MT)) * 1024 : 0;   // K-slice exchange buffer
   // as many channel chunks per fill as fit in ~72 KiB (two workgroups per CU stay resident)
   int cpf = (72 * 1024) / chunk_bytes;
   if (cpf < 1) cpf = 1;
@@ -555,6 +597,10 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = (char*)h_out; a.gates_out = (char*)gates_out;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
   a.tile_rows = ly->tile_rows;
+#ifdef NINT_EXPERIMENT
+  a.dbg = ly->tile_rows >> 8;                 // experiment build: selector in the upper bits
+  a.tile_rows = ly->tile_rows & 0xff;
+#endif
   hipStream_t st = (hipStream_t)stream;
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st);

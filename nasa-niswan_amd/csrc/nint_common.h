@@ -149,8 +149,14 @@ struct ConvArgs {
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                      float* db_partial, bool dc_zero, void* stream);
-int nint_internal_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, const void* x_slab,
-                             const void* h_slab, float* dW, float* db, float* partial, size_t partial_bytes, int n_cu,
-                             const float* db_partial, int db_rows, int h_skip, void* stream);
+struct WgJob {           // one layer's weight / bias gradient
+  const nint_layer* ly; int N;
+  const void* dG; const void* x_slab; const void* h_slab;
+  float* dW; float* db;
+  const float* db_partial; int db_rows;      // fused bias-gradient partial rows (or NULL: column-sum pass over dG)
+  int h_skip;                                // leading images whose h source is identically zero
+};
+int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
+                                   size_t partial_bytes, int n_cu, void* stream);
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
                              void* dh_prev, bool overwrite_dx, void* stream);

@@ -297,9 +297,9 @@ extern "C" int nint_unpack_compact(const void* src, float* dst, int N, int C, in
 // K-channel kc = kx*Cx + c selects W[.][c][ky][kx]; in the dgrad image the folded x columns take their weight
 // at the centre-column taps (tx = k/2) and zero elsewhere.
 template <int DT>
-__global__ void pack_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias, void* __restrict__ Wf,
-                                    void* __restrict__ Wd, float* __restrict__ bias_p, int Cx, int Cxp, int Ch, int Ch16,
-                                    int Chp, int k, int xfold) {
+__device__ __forceinline__ void pack_weights_body(const float* __restrict__ W, const float* __restrict__ bias, void* __restrict__ Wf,
+                                                  void* __restrict__ Wd, float* __restrict__ bias_p, int Cx, int Cxp, int Ch, int Ch16,
+                                                  int Chp, int k, int xfold) {
   typedef Elem<DT> E;
   const int taps = k * k;
   const int Ctot = Cx + Ch;
@@ -380,6 +380,22 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, const float* __
   }
 }
 
+template <int DT>
+__global__ void pack_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias, void* __restrict__ Wf,
+                                    void* __restrict__ Wd, float* __restrict__ bias_p, int Cx, int Cxp, int Ch, int Ch16,
+                                    int Chp, int k, int xfold) {
+  pack_weights_body<DT>(W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k, xfold);
+}
+
+// every layer of a model in one launch: layer = blockIdx.y
+struct PackEntry { const float* W; const float* bias; void* Wf; void* Wd; float* bias_p; int Cx, Cxp, Ch, Ch16, Chp, k, xfold; };
+struct PackTable { PackEntry e[NINT_MAX_LAYERS]; };
+template <int DT>
+__global__ void pack_weights_layers_kernel(PackTable t) {
+  const PackEntry& E = t.e[blockIdx.y];
+  pack_weights_body<DT>(E.W, E.bias, E.Wf, E.Wd, E.bias_p, E.Cx, E.Cxp, E.Ch, E.Ch16, E.Chp, E.k, E.xfold);
+}
+
 extern "C" int nint_kc(int dtype) { return dtype == NINT_BF16 ? 32 : (dtype == NINT_F32 ? 16 : NINT_E_ARG); }
 
 // Folding pays when it lowers the number of x K-steps: ceil(k*Cx / KC) * k  <  ceil(Cx / KC) * k * k
@@ -410,6 +426,31 @@ extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, vo
     hipLaunchKernelGGL(pack_weights_kernel<NINT_BF16>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k, xfold);
   else
     hipLaunchKernelGGL(pack_weights_kernel<NINT_F32>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k, xfold);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+extern "C" int nint_pack_weights_layers(const float* const* W, const float* const* bias, const nint_layer* layers, int L,
+                                        int dtype, void* stream) {
+  if (!W || !bias || !layers || L < 1 || L > NINT_MAX_LAYERS) return NINT_E_ARG;
+  const int kc = nint_kc(dtype);
+  if (kc < 0) return NINT_E_ARG;
+  PackTable t = {};
+  size_t nmax = 0;
+  for (int l = 0; l < L; ++l) {
+    const nint_layer& ly = layers[l];
+    if (!W[l] || !ly.Wf || !ly.Wd || !ly.bias_p || ly.Cx <= 0 || ly.Ch <= 0 || !(ly.k & 1)) return NINT_E_ARG;
+    if (ly.Cxp != nint_round_up(ly.xfold ? ly.k * ly.Cx : ly.Cx, kc) || ly.Chp != nint_round_up(ly.Ch, kc) ||
+        ly.Ch16 != nint_round_up(ly.Ch, 16))
+      return NINT_E_ARG;
+    t.e[l] = PackEntry{W[l], bias[l], (void*)ly.Wf, (void*)ly.Wd, (float*)ly.bias_p, ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k, ly.xfold};
+    const size_t n = 2 * (size_t)(ly.Cxp + ly.Chp) * 4 * ly.Ch16 * ly.k * ly.k + 4 * ly.Ch16;
+    if (n > nmax) nmax = n;
+  }
+  dim3 grid = grid1d(nmax);
+  grid.y = L;
+  if (dtype == NINT_BF16) hipLaunchKernelGGL(pack_weights_layers_kernel<NINT_BF16>, grid, dim3(256), 0, (hipStream_t)stream, t);
+  else hipLaunchKernelGGL(pack_weights_layers_kernel<NINT_F32>, grid, dim3(256), 0, (hipStream_t)stream, t);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
@@ -861,6 +902,7 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const double* __restric
 // tail of `stats` would complicate the ABI, so the kernel pair uses dpred-independent scratch
 // carved from loss_out[1..]: loss_out must have room for 1 + 2*LOSS_BLOCKS*4 floats.
 #define LOSS_BLOCKS 256
+#define LOSS_BLOCKS_MAX ((NINT_LOSS_SCRATCH_FLOATS - 2) / 8)     // what the caller's scratch holds: 4 doubles per workgroup
 extern "C" int nint_loss_mse_l1_crop(const float* pred, const float* y, float* dpred, float* loss_out, double* stats,
                                      int N, int O, int H, int W, int oy, int ox, int Hc, int Wc, void* stream) {
   if (!pred || !y || !loss_out || N <= 0 || O <= 0 || oy < 0 || ox < 0 || oy + Hc > H || ox + Wc > W) return NINT_E_ARG;
@@ -870,6 +912,97 @@ extern "C" int nint_loss_mse_l1_crop(const float* pred, const float* y, float* d
   hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(1024), 0, st, pred, y, dpred, partial, N, O, H, W, oy, ox, Hc, Wc);
   NINT_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, LOSS_BLOCKS, loss_out, stats, (double)N * O * Hc * Wc);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
+// ------------------------------------------------------------------------------ head + loss, fused (training)
+// train.py:96-109 around the 1x1 head in ONE pass over the pixels: pred = w . h + b (model.py:274), crop, the MSE+L1
+// partial sums (train.py:102,105), d loss / d pred, and dL/dh = w^T . dpred.  One thread per pixel (grid-stride):
+// the channel vector is read once, pred never goes to memory, dpred is written for the head's weight gradient.
+// Same arithmetic, in the same order, as head_fwd_kernel -> loss_partial_kernel -> head_bwd_dh_kernel.
+template <int DT, int CHV>
+__global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp, int O,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              const float* __restrict__ y, float* __restrict__ dpred,
+                                                              void* __restrict__ dh, double* __restrict__ partial, int H, int W,
+                                                              int P, int Hh, int Wh, int oy, int ox, int Hc, int Wc) {
+  const size_t npix = (size_t)N * H * W;
+  const double inv_n = 1.0 / ((double)N * O * Hc * Wc);
+  double s2 = 0, s1 = 0, sy = 0, syy = 0;
+  for (size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    const int x = pix % W;
+    size_t r = pix / W;
+    const int yy = r % H;
+    const int n = r / H;
+    const size_t hb = ((((size_t)(n0 + n)) * Hh + (yy + P)) * Wh + (x + P)) * Chp;
+    float hv[CHV], acc[CHV];
+#pragma unroll
+    for (int c = 0; c < CHV; c += 4) {
+      const f32x4_t v = (c < Chp) ? load_vec4<DT>(h, hb + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      hv[c] = v[0]; hv[c + 1] = v[1]; hv[c + 2] = v[2]; hv[c + 3] = v[3];
+      acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.f;
+    }
+    const int cy = yy - oy, cx = x - ox;
+    const bool in = cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+    float* dp = dpred + ((size_t)n * O * H + yy) * W + x;
+    const float* yp = y + ((size_t)n * O * Hc + cy) * Wc + cx;
+    for (int o = 0; o < O; ++o) {
+      float p = b ? b[o] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CHV; ++c)
+        if (c < Ch) p += w[o * Ch + c] * hv[c];
+      float gq = 0.f;
+      if (in) {
+        const float t = yp[(size_t)o * Hc * Wc];
+        const float d = p - t;
+        s2 += (double)d * d;
+        s1 += fabs((double)d);
+        sy += t;
+        syy += (double)t * t;
+        gq = (float)((2.0 * d + (d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0))) * inv_n);
+      }
+      dp[(size_t)o * H * W] = gq;
+#pragma unroll
+      for (int c = 0; c < CHV; ++c)
+        if (c < Ch) acc[c] += w[o * Ch + c] * gq;
+    }
+#pragma unroll
+    for (int c = 0; c < CHV; c += 4)
+      if (c < Chp) store_vec4<DT>(dh, pix * Chp + c, (f32x4_t){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+  }
+  __shared__ double red[4][256];
+  red[0][threadIdx.x] = s2; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = sy; red[3][threadIdx.x] = syy;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+extern "C" int nint_head_loss_fused(const void* h_slab, int n0, int N, int Ch, int Chp, int O, const float* w, const float* b,
+                                    const float* y, float* dpred, void* dh, float* loss_out, double* stats, const nint_geom* g,
+                                    int oy, int ox, int Hc, int Wc, int dtype, void* stream) {
+  if (!h_slab || !w || !y || !dpred || !dh || !loss_out || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
+  if (oy < 0 || ox < 0 || oy + Hc > g->H || ox + Wc > g->W) return NINT_E_ARG;
+  if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
+  if (Chp > 64 || Chp % 4) return NINT_E_SHAPE;           // wider heads: nint_head_fwd + nint_loss_mse_l1_crop + nint_head_bwd
+  if ((((uintptr_t)loss_out) & 7) != 0) return NINT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)(loss_out + 2);   // loss_out: [0]=loss, [1]=pad, [2..] = up to LOSS_BLOCKS_MAX*4 doubles
+  // one pixel per thread (the per-pixel loop over the outputs is long): up to LOSS_BLOCKS_MAX workgroups
+  const size_t npix = (size_t)N * g->H * g->W;
+  const int nblk = (int)((npix + 255) / 256 < LOSS_BLOCKS_MAX ? (npix + 255) / 256 : LOSS_BLOCKS_MAX);
+  const dim3 grid(nblk);
+#define NINT_HL(DT_, CHV_) hipLaunchKernelGGL((head_loss_fused_kernel<DT_, CHV_>), grid, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, \
+                                              y, dpred, dh, partial, g->H, g->W, g->P, g->Hh, g->Wh, oy, ox, Hc, Wc)
+  if (dtype == NINT_BF16) { if (Chp <= 32) NINT_HL(NINT_BF16, 32); else NINT_HL(NINT_BF16, 64); }
+  else { if (Chp <= 32) NINT_HL(NINT_F32, 32); else NINT_HL(NINT_F32, 64); }
+#undef NINT_HL
+  NINT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, nblk, loss_out, stats, (double)N * O * Hc * Wc);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }

@@ -173,17 +173,18 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       if (rc != NINT_OK) return rc;
     }
   }
-  // weight / bias gradients: ONE reduction over all T time steps per layer and source
+  // weight / bias gradients: ONE reduction over all T time steps per layer and source, all layers' folds merged
+  WgJob jobs[NINT_MAX_LAYERS];
   for (int l = 0; l < L; ++l) {
     const nint_layer* ly = &s->layer[l];
     const bool fused_db = s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0;
     const char* x_all = (l == 0) ? (const char*)s->xs
                                  : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
     // h_{-1} = 0 for a sequence from the zero state: the h part of the reduction skips time step 0
-    rc = nint_internal_conv_wgrad(ly, g, s->dtype, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
-                                  s->wg_partial, s->wg_partial_bytes, s->n_cu, fused_db ? s->db_partial[l] : nullptr,
-                                  s->T * NINT_DB_ROWS, s->has_init_state ? 0 : B, stream);
-    if (rc != NINT_OK) return rc;
+    jobs[l] = WgJob{ly, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
+                    fused_db ? s->db_partial[l] : nullptr, s->T * NINT_DB_ROWS, s->has_init_state ? 0 : B};
   }
+  rc = nint_internal_conv_wgrad_multi(jobs, L, g, s->dtype, s->wg_partial, s->wg_partial_bytes, s->n_cu, stream);
+  if (rc != NINT_OK) return rc;
   return NINT_OK;
 }

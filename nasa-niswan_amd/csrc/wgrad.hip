@@ -259,16 +259,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // elements of the slab layout [block][j][n'loc 64][c 16] (one 256-byte line per split, fully coalesced) and
 // spreads the splits over its blockDim/64 waves; the per-wave sums are folded through LDS.  The order is a
 // fixed function of the launch shape (bitwise reproducible); only the single write per weight is scattered.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Cx, int Ch, int Ch16, int k,
-                                    int NB, int CB, int NTC, int J, int splits, int is_h, int xfold) {
+struct ReduceEntry {
+  const float* part; float* dW;
+  int Cx, Ch, Ch16, k, NB, CB, NTC, J, splits, is_h, xfold;
+  int waves;                                // waves that share the splits of one 64-element line (the others exit)
+  unsigned blk_begin;                       // first workgroup of this (layer, source) in the merged launch
+};
+struct ReduceTable { ReduceEntry e[2 * NINT_MAX_LAYERS]; int n; };
+
+__global__ void wgrad_reduce_kernel(ReduceTable t) {
   __shared__ float red[1024];
+  int ei = 0;
+  for (int q = 1; q < t.n; ++q) ei = blockIdx.x >= t.e[q].blk_begin ? q : ei;     // entries are in launch order
+  const ReduceEntry& E = t.e[ei];
+  const int Cx = E.Cx, Ch = E.Ch, k = E.k, CB = E.CB, NTC = E.NTC, J = E.J, splits = E.splits, is_h = E.is_h;
+  const float* __restrict__ part = E.part;
+  float* __restrict__ dW = E.dW;
   const int taps = k * k, Ctot = Cx + Ch;
-  const size_t slab = (size_t)NB * CB * J * 1024;
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, G = blockDim.x >> 6;
-  const size_t i = (size_t)blockIdx.x * 64 + lane;       // slab is a multiple of 1024: no tail
+  const size_t slab = (size_t)E.NB * CB * J * 1024;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, G = E.waves;   // waves >= G idle through the barrier
+  const size_t i = (size_t)(blockIdx.x - E.blk_begin) * 64 + lane;       // slab is a multiple of 1024: no tail
   float s = 0.f;
+  if (grp < G) {
 #pragma unroll 4
-  for (int sp = grp; sp < splits; sp += G) s += part[i + (size_t)sp * slab];
+    for (int sp = grp; sp < splits; sp += G) s += part[i + (size_t)sp * slab];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (grp != 0) return;
@@ -284,7 +299,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
   const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
   int Csrc = is_h ? Ch : Cx;
-  if (!is_h && xfold) {                               // folded x source: column (ky, kx*Cx + c) -> W[.][c][ky][kx]
+  if (!is_h && E.xfold) {                             // folded x source: column (ky, kx*Cx + c) -> W[.][c][ky][kx]
     if (cc >= k * Cx) return;
     tap = tap * k + cc / Cx;
     cc = cc % Cx;
@@ -294,10 +309,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
 }
 
-// column sums of a row-major f32 matrix [rows][ld] over columns [64*blockIdx.x, +64): block = 64 columns x
-// blockDim/64 row lanes, grid.y row groups; partial[blockIdx.y][ld].  Fixed order.
-__global__ void rowsum_partial_kernel(const float* __restrict__ m, float* __restrict__ partial, int rows, int ld) {
+struct BiasEntry { const float* m; float* partial; float* db; int rows, ld, Ch; };     // one layer's bias-gradient fold
+struct BiasTable { BiasEntry e[NINT_MAX_LAYERS]; int n; };
+
+// column sums of row-major f32 matrices [rows][ld] (the bias-gradient partial rows of layer blockIdx.z) over columns
+// [64*blockIdx.x, +64): block = 64 columns x blockDim/64 row lanes, grid.y row groups; partial[blockIdx.y][ld].  Fixed order.
+__global__ void rowsum_partial_kernel(BiasTable t) {
   __shared__ float red[1024];
+  const BiasEntry& E = t.e[blockIdx.z];
+  if (!E.m) return;                                                       // this layer's partial rows come from colsum_partial_kernel
+  const int ld = E.ld, rows = E.rows;
+  if ((int)blockIdx.x * 64 >= ld) return;
+  const float* __restrict__ m = E.m;
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, G = blockDim.x >> 6;
   float acc = 0.f;
   if (col < ld) {
@@ -308,7 +331,7 @@ __global__ void rowsum_partial_kernel(const float* __restrict__ m, float* __rest
   __syncthreads();
   if (sub != 0 || col >= ld) return;
   for (int q = 1; q < G; ++q) acc += red[q * 64 + (threadIdx.x & 63)];
-  partial[(size_t)blockIdx.y * ld + col] = acc;
+  E.partial[(size_t)blockIdx.y * ld + col] = acc;
 }
 
 // db[o] = sum over all pixels of dG[.,o]: grid = (row splits, column groups of 64); fixed order.
@@ -331,23 +354,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
   if (sub == 0) partial[((size_t)blockIdx.x * gridDim.y + colgrp) * 64 + col] = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
 }
 
-// db[o] = sum of the partial rows; block = 64 outputs x blockDim/64 row lanes
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ db, int Ch, int Gc, int nrows) {
+// db[o] = sum of the partial rows of layer blockIdx.y; block = 64 outputs x blockDim/64 row lanes
+__global__ void colsum_final_kernel(BiasTable t, int nrows) {
   __shared__ float red[1024];
+  const BiasEntry& E = t.e[blockIdx.y];
+  const int Ch = E.Ch, Gc = E.ld;
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, G = blockDim.x >> 6;
+  if ((int)blockIdx.x * 64 >= 4 * Ch) return;
   const bool ok = o < 4 * Ch;
   float s = 0.f;
   if (ok) {
     const int gate = o / Ch, ch = o % Ch;
     const int np = (ch >> 4) * 64 + gate * 16 + (ch & 15);
 #pragma unroll 4
-    for (int r = sub; r < nrows; r += G) s += partial[(size_t)r * Gc + np];
+    for (int r = sub; r < nrows; r += G) s += E.partial[(size_t)r * Gc + np];
   }
   red[threadIdx.x] = s;
   __syncthreads();
   if (sub != 0 || !ok) return;
   for (int q = 1; q < G; ++q) s += red[q * 64 + (threadIdx.x & 63)];
-  db[o] = s;
+  E.db[o] = s;
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -441,74 +467,100 @@ static int dispatch_wgrad(WgradArgs& a, const WgPart& w, int nblk, hipStream_t s
   }
 }
 
+// Weight / bias gradients of several layers ("jobs") in one go: two MFMA launches per layer (x and h source) into
+// consecutive regions of ONE workspace, then ONE launch folds every split-K slab of every layer into its dW, one
+// launch column-sums all bias-gradient partial rows and one finishes them (12 launches -> 3 for a 3-layer model).
 // h_skip: the first h_skip images have an identically zero h source (h_{-1} = 0 of a sequence that starts from
 // the zero state, model.py:259-262): the h part skips them -- 1/T of its work.
-int nint_internal_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, const void* x_slab,
-                             const void* h_slab, float* dW, float* db, float* partial, size_t partial_bytes, int n_cu,
-                             const float* db_partial, int db_rows, int h_skip, void* stream) {
-  if (!ly || !g || !dG || !x_slab || !h_slab || !dW || !db || !partial || N <= 0) return NINT_E_ARG;
-  if (h_skip < 0 || h_skip > N) return NINT_E_ARG;
+int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
+                                   size_t partial_bytes, int n_cu, void* stream) {
+  if (!jobs || njobs < 1 || njobs > NINT_MAX_LAYERS || !g || !partial) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
-  WgPlan pl;
-  int rc = wg_plan(ly, dtype, n_cu, N, g, &pl);
-  if (rc != NINT_OK) return rc;
-  if (pl.total_floats * sizeof(float) > partial_bytes) return NINT_E_ARG;
   const int es = dtype == NINT_BF16 ? 2 : 4;
-  const int Gc = 4 * ly->Ch16;
   hipStream_t st = (hipStream_t)stream;
-  for (int part = 0; part < 2; ++part) {
-    const WgPart& w = pl.part[part];
-    WgradArgs a = {};
-    a.dG_pix_stride = Gc * es;
-    a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
-    const int skip = part == 1 ? h_skip : 0;
-    a.dG = (const char*)dG + (size_t)skip * a.dG_img_stride;
-    const int Cp = part == 0 ? ly->Cxp : ly->Chp;
-    a.src_pix_stride = Cp * es;
-    a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
-    a.src = (const char*)(part == 0 ? x_slab : h_slab) + (size_t)skip * a.src_img_stride;
-    a.partial = partial + (part == 0 ? 0 : pl.off_h);
-    a.CB = w.CB;
-    a.NTC = w.NTC; a.J = w.J;
-    a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * w.KX;
-    a.P = g->P; a.Wh = g->Wh;
-    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
-    a.ntiles = (N - skip) * pl.tiles_x * pl.tiles_y;  // empty splits flush zeros
-    a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
-    const int nblk = pl.NB * a.CB;
-    rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);
+  ReduceTable rt = {};
+  BiasTable bt = {};
+  bt.n = njobs;
+  size_t off = 0;
+  unsigned blk = 0;
+  int red_threads = 256, max_gc64 = 0, max_o64 = 0, db_rows_out = 64;
+  bool any_rows = false;
+  for (int q = 0; q < njobs; ++q) {
+    const WgJob& jb = jobs[q];
+    const nint_layer* ly = jb.ly;
+    if (!ly || !jb.dG || !jb.x_slab || !jb.h_slab || !jb.dW || !jb.db || jb.N <= 0) return NINT_E_ARG;
+    if (jb.h_skip < 0 || jb.h_skip > jb.N) return NINT_E_ARG;
+    WgPlan pl;
+    int rc = wg_plan(ly, dtype, n_cu, jb.N, g, &pl);
     if (rc != NINT_OK) return rc;
-  }
-  // fold the split-K slabs into dW, and the bias gradient from the fused pointwise partial rows (or a column-sum pass over dG)
-  for (int part = 0; part < 2; ++part) {
-    const WgPart& w = pl.part[part];
-    const size_t slab = (size_t)pl.NB * w.CB * w.J * 1024;
-    // few large slabs: 4 waves share the splits; many small slabs: 16 waves
-    const int threads = w.splits >= 64 ? 1024 : 256;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(slab / 64)), dim3(threads), 0, st, partial + (part == 0 ? 0 : pl.off_h), dW,
-                       ly->Cx, ly->Ch, ly->Ch16, ly->k, pl.NB, w.CB, w.NTC, w.J, w.splits, part, ly->xfold);
-    NINT_LAUNCH_CHECK();
-  }
-  {
-    float* dbp = partial + pl.off_db;          // (the workspace's tail is the scratch of the bias fold)
-    dim3 grid(pl.db_rows, Gc / 64);
-    if (db_partial) {
-      hipLaunchKernelGGL(rowsum_partial_kernel, dim3(Gc / 64, pl.db_rows), dim3(1024), 0, st, db_partial, dbp, db_rows, Gc);
-    } else if (dtype == NINT_BF16) {
-      hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
-    } else {
-      hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, dG, dbp, N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+    if ((off + pl.total_floats) * sizeof(float) > partial_bytes) return NINT_E_ARG;
+    float* base = partial + off;
+    off += (pl.total_floats + 63) / 64 * 64;
+    const int Gc = 4 * ly->Ch16;
+    for (int part = 0; part < 2; ++part) {
+      const WgPart& w = pl.part[part];
+      WgradArgs a = {};
+      a.dG_pix_stride = Gc * es;
+      a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
+      const int skip = part == 1 ? jb.h_skip : 0;
+      a.dG = (const char*)jb.dG + (size_t)skip * a.dG_img_stride;
+      const int Cp = part == 0 ? ly->Cxp : ly->Chp;
+      a.src_pix_stride = Cp * es;
+      a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
+      a.src = (const char*)(part == 0 ? jb.x_slab : jb.h_slab) + (size_t)skip * a.src_img_stride;
+      a.partial = base + (part == 0 ? 0 : pl.off_h);
+      a.CB = w.CB;
+      a.NTC = w.NTC; a.J = w.J;
+      a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * w.KX;
+      a.P = g->P; a.Wh = g->Wh;
+      a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
+      a.ntiles = (jb.N - skip) * pl.tiles_x * pl.tiles_y;  // empty splits flush zeros
+      a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
+      const int nblk = pl.NB * a.CB;
+      rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);
+      if (rc != NINT_OK) return rc;
+      ReduceEntry& E = rt.e[rt.n++];
+      E.part = a.partial; E.dW = jb.dW;
+      E.Cx = ly->Cx; E.Ch = ly->Ch; E.Ch16 = ly->Ch16; E.k = ly->k; E.NB = pl.NB; E.CB = w.CB; E.NTC = w.NTC; E.J = w.J;
+      E.splits = w.splits; E.is_h = part; E.xfold = ly->xfold;
+      E.blk_begin = blk;
+      blk += (unsigned)((size_t)pl.NB * w.CB * w.J * 1024 / 64);
+      E.waves = w.splits >= 64 ? 16 : 4;         // few large slabs: 4 waves share the splits; many small slabs: 16 waves
+      if (E.waves * 64 > red_threads) red_threads = E.waves * 64;
     }
-    NINT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(nint_cdiv(4 * ly->Ch, 64)), dim3(1024), 0, st, dbp, db, ly->Ch, Gc, pl.db_rows);
+    BiasEntry& B = bt.e[q];
+    B.partial = base + pl.off_db;              // (the region's tail is the scratch of the bias fold)
+    B.db = jb.db; B.ld = Gc; B.Ch = ly->Ch;
+    db_rows_out = pl.db_rows;
+    if (jb.db_partial) {
+      B.m = jb.db_partial; B.rows = jb.db_rows;
+      any_rows = true;
+    } else {                                   // no fused partial rows for this shape: a column-sum pass over dG
+      B.m = nullptr; B.rows = 0;
+      dim3 grid(pl.db_rows, Gc / 64);
+      if (dtype == NINT_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, jb.dG, B.partial, jb.N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+      else
+        hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, jb.dG, B.partial, jb.N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
+      NINT_LAUNCH_CHECK();
+    }
+    if (Gc / 64 > max_gc64) max_gc64 = Gc / 64;
+    if (nint_cdiv(4 * ly->Ch, 64) > max_o64) max_o64 = nint_cdiv(4 * ly->Ch, 64);
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blk), dim3(red_threads), 0, st, rt);
+  NINT_LAUNCH_CHECK();
+  if (any_rows) {
+    hipLaunchKernelGGL(rowsum_partial_kernel, dim3(max_gc64, db_rows_out, njobs), dim3(1024), 0, st, bt);
     NINT_LAUNCH_CHECK();
   }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(max_o64, njobs), dim3(1024), 0, st, bt, db_rows_out);
+  NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
 
 extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG,
                                const void* x_slab, const void* h_slab, float* dW, float* db, float* partial,
                                size_t partial_bytes, int n_cu, const float* db_partial, int db_rows, void* stream) {
-  return nint_internal_conv_wgrad(ly, g, dtype, N, dG, x_slab, h_slab, dW, db, partial, partial_bytes, n_cu, db_partial, db_rows, 0,
-                                  stream);
+  const WgJob jb = {ly, N, dG, x_slab, h_slab, dW, db, db_partial, db_rows, 0};
+  return nint_internal_conv_wgrad_multi(&jb, 1, g, dtype, partial, partial_bytes, n_cu, stream);
 }

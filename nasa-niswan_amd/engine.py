@@ -143,8 +143,8 @@ class SeqEngine:
             ly.Wf, ly.Wd, ly.bias_p = self.Wf[-1].data_ptr(), self.Wd[-1].data_ptr(), self.bias_p[-1].data_ptr()
             self.layers.append(ly)
             ly.tile_rows = FORCE_TILE_ROWS
-            # one split-K workspace serves every layer in turn (the reductions run back to back on one stream)
-            wg_bytes = max(wg_bytes, (self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256)
+            # the layers' split-K slabs sit side by side in one workspace: one launch folds them all
+            wg_bytes += (self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256
         # shapes the weight-gradient kernel has no instantiation for: known NOW, reported at the first training
         # workspace (forward / inference work for every odd k) instead of as a shape error in the first backward()
         self.train_unsupported = self.untrainable_layers(self.cfgs, self.dt, self.n_cu)
@@ -160,7 +160,9 @@ class SeqEngine:
 
     # ------------------------------------------------------------------ weights
     def pack_weights(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
-        st = stream_ptr()
+        """OIHW f32 conv weights of every layer -> MFMA fragment order (fwd + dgrad images) and permuted bias: one launch."""
+        L = len(self.cfgs)
+        Ws, bs = [], []
         for l, cfg in enumerate(self.cfgs):
             W = weights[l].detach()
             if W.dtype != torch.float32 or not W.is_contiguous():
@@ -171,8 +173,11 @@ class SeqEngine:
                 b = b.detach()
                 if b.dtype != torch.float32 or not b.is_contiguous():
                     b = b.float().contiguous()
-            check(self.lib.nint_pack_weights(ptr(W), ptr(b), ptr(self.Wf[l]), ptr(self.Wd[l]), ptr(self.bias_p[l]),
-                                             cfg.Cx, cfg.Ch, cfg.k, int(cfg.xfold), self.dt, st), "nint_pack_weights")
+            Ws.append(W); bs.append(b)
+        wp = (C.c_void_p * L)(*[W.data_ptr() for W in Ws])
+        bp = (C.c_void_p * L)(*[None if b is None else b.data_ptr() for b in bs])
+        lys = (NintLayer * L)(*self.layers)
+        check(self.lib.nint_pack_weights_layers(wp, bp, lys, L, self.dt, stream_ptr()), "nint_pack_weights_layers")
 
     @staticmethod
     def untrainable_layers(cfgs: Sequence[LayerCfg], dtype, n_cu: int = 256) -> List[str]:
@@ -282,8 +287,27 @@ class SeqEngine:
                                      C.byref(ws.g), self.dt, stream_ptr()), "nint_head_fwd")
         return pred
 
-    def head_backward(self, ws: Workspace, w: torch.Tensor, dpred: torch.Tensor, dw_out=None, db_out=None):
-        """Writes dL/dh_{T-1} of the last layer into ws.dh[-1]; returns (dw_head, db_head)."""
+    def head_loss_fused(self, ws: Workspace, w: torch.Tensor, b: Optional[torch.Tensor], y: torch.Tensor, dpred: torch.Tensor,
+                        scratch: torch.Tensor, stats: torch.Tensor, halo, Hc: int, Wc: int) -> bool:
+        """Training fast path (nint_head_loss_fused): head forward, crop, MSE+L1 sums, d loss / d pred and dL/dh_{T-1}
+        (into ws.dh[-1]) in one pass; `scratch[0]` = loss, `stats` accumulated.  False when the head is wider than the
+        fused kernel holds in registers (the caller then takes the three separate launches)."""
+        l = len(self.cfgs) - 1
+        cfg = self.cfgs[l]
+        Chp = cfg.padded(self.kc)[2]
+        if Chp > 64:
+            return False
+        O = w.shape[0]
+        w2 = w.detach().float().contiguous()
+        b2 = None if b is None else b.detach().float().contiguous()
+        check(self.lib.nint_head_loss_fused(ptr(ws.h[l]), ws.T * ws.B, ws.B, cfg.Ch, Chp, O, ptr(w2), ptr(b2), ptr(y), ptr(dpred),
+                                            ptr(ws.dh[l]), ptr(scratch), ptr(stats), C.byref(ws.g), halo[0], halo[1], Hc, Wc,
+                                            self.dt, stream_ptr()), "nint_head_loss_fused")
+        return True
+
+    def head_backward(self, ws: Workspace, w: torch.Tensor, dpred: torch.Tensor, dw_out=None, db_out=None, write_dh: bool = True):
+        """Writes dL/dh_{T-1} of the last layer into ws.dh[-1] (unless `write_dh` is False: the fused head/loss pass
+        already did); returns (dw_head, db_head)."""
         l = len(self.cfgs) - 1
         cfg = self.cfgs[l]
         Chp = cfg.padded(self.kc)[2]
@@ -292,7 +316,8 @@ class SeqEngine:
         dp = dpred.detach().float().contiguous()
         dw = dw_out if dw_out is not None else torch.empty(O, cfg.Ch, dtype=torch.float32, device=self.device)
         db = db_out if db_out is not None else torch.empty(O, dtype=torch.float32, device=self.device)
-        check(self.lib.nint_head_bwd(ptr(ws.h[l]), ws.T * ws.B, ws.B, cfg.Ch, Chp, O, ptr(w2), ptr(dp), ptr(ws.dh[l]),
+        check(self.lib.nint_head_bwd(ptr(ws.h[l]), ws.T * ws.B, ws.B, cfg.Ch, Chp, O, ptr(w2), ptr(dp),
+                                     ptr(ws.dh[l]) if write_dh else None,
                                      ptr(dw), ptr(db), C.byref(ws.g), self.dt, ptr(self.wg_partial),
                                      self.wg_partial.numel() * 4, stream_ptr()), "nint_head_bwd")
         return dw.view(O, cfg.Ch, 1, 1), db

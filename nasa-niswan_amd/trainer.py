@@ -81,10 +81,30 @@ class FusedTrainer:
         return eng, ws, pred, dpred
 
     def step(self, X: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        """One optimisation step; returns the loss as a 0-dim DEVICE tensor (no sync)."""
-        eng, ws, pred, dpred = self.forward_loss(X, y, True)
-        L = self.model.num_layers
-        eng.head_backward(ws, self.model.conv.weight, dpred, dw_out=self._dw_head, db_out=self._db_head)
+        """One optimisation step; returns the loss as a 0-dim DEVICE tensor (no sync).  X: (B,T,C,Hp,Wp) f32 or a
+        dataset.SlabBatch."""
+        m = self.model
+        eng = m._engine(self.device)
+        B, T, _, H, W = X.shape
+        L = m.num_layers
+        ws = eng.acquire(B, T, H, W, True, False)
+        eng.pack_weights([c.conv.weight for c in m.layers], [c.conv.bias for c in m.layers])
+        eng.forward(ws, X)
+        O = m.conv.weight.shape[0]
+        Hc, Wc = y.shape[-2], y.shape[-1]
+        yv = y.detach().float().contiguous()
+        assert yv.numel() == B * O * Hc * Wc, "target must be (B,[O,]Hc,Wc)"
+        if self._dpred is None or self._dpred.shape != (B, O, H, W):
+            self._dpred = torch.empty(B, O, H, W, dtype=torch.float32, device=self.device)
+        dpred = self._dpred
+        # head forward + crop + loss + dpred + dL/dh in one pass; the prediction itself is never materialised
+        fused = eng.head_loss_fused(ws, m.conv.weight, m.conv.bias, yv, dpred, self.scratch, self.stats, self.halo, Hc, Wc)
+        if not fused:
+            pred = eng.head_forward(ws, m.conv.weight, m.conv.bias)
+            check(self.lib.nint_loss_mse_l1_crop(ptr(pred), ptr(yv), ptr(dpred), ptr(self.scratch), ptr(self.stats),
+                                                 B, O, H, W, self.halo[0], self.halo[1], Hc, Wc, stream_ptr()),
+                  "nint_loss_mse_l1_crop")
+        eng.head_backward(ws, m.conv.weight, dpred, dw_out=self._dw_head, db_out=self._db_head, write_dh=not fused)
         eng.backward(ws, False, zero_state_grads=range(L), dW_out=self._dW, db_out=self._db)
         eng.release(ws)
         if self.distributed:

@@ -127,6 +127,50 @@ def test_loss_mse_l1_crop_matches_oracle(lib):
         assert abs(r2 - O.r2_score_np(y.numpy(), pc.numpy())) < 1e-7
 
 
+@pytest.mark.parametrize("dt,Ch,O", [(0, 16, 20), (1, 16, 20), (1, 8, 1), (0, 48, 3)])
+def test_head_loss_fused_equals_the_three_separate_launches(lib, dt, Ch, O):
+    """The training fast path nint_head_loss_fused (head forward + crop + MSE/L1 sums + dpred + dL/dh in one pass) must
+    be bit-identical to nint_head_fwd -> nint_loss_mse_l1_crop -> nint_head_bwd, which the oracle tests pin; the
+    loss also against the oracle directly."""
+    from oracle import convlstm_oracle as O_
+    N, H, W, Pd, halo = 3, 20, 28, 2, (5, 4)
+    Hc, Wc = H - 2 * halo[0], W - 2 * halo[1]
+    g = geom(lib, H, W, Pd)
+    kc = lib.nint_kc(dt)
+    Chp = (Ch + kc - 1) // kc * kc
+    es = 2 if dt else 4
+    et = torch.bfloat16 if dt else torch.float32
+    hsl = torch.zeros(2 * N, g.Hh, g.Wh, Chp, device="cuda", dtype=et)
+    hsl[:, Pd:Pd + H, Pd:Pd + W, :Ch] = torch.randn(2 * N, H, W, Ch, device="cuda").to(et)
+    w = torch.randn(O, Ch, device="cuda") * 0.3
+    b = torch.randn(O, device="cuda")
+    y = torch.randn(N, O, Hc, Wc, device="cuda")
+    n0 = N                                                        # the head reads images [n0, n0+N)
+    # separate launches
+    pred = torch.empty(N, O, H, W, device="cuda")
+    assert lib.nint_head_fwd(P(hsl), n0, N, Ch, Chp, O, P(w), P(b), P(pred), C.byref(g), dt, None) == 0
+    dp1, sc1, st1 = torch.empty_like(pred), torch.zeros(8194, device="cuda"), torch.zeros(8, dtype=torch.float64, device="cuda")
+    assert lib.nint_loss_mse_l1_crop(P(pred), P(y), P(dp1), P(sc1), P(st1), N, O, H, W, halo[0], halo[1], Hc, Wc, None) == 0
+    dh1 = torch.zeros(N * H * W * Chp, device="cuda", dtype=et)
+    assert lib.nint_head_bwd(P(hsl), n0, N, Ch, Chp, O, P(w), P(dp1), P(dh1), None, None, C.byref(g), dt, None, 0, None) == 0
+    # fused
+    dp2, sc2, st2 = torch.empty_like(pred), torch.zeros(8194, device="cuda"), torch.zeros(8, dtype=torch.float64, device="cuda")
+    dh2 = torch.zeros(N * H * W * Chp, device="cuda", dtype=et)
+    assert lib.nint_head_loss_fused(P(hsl), n0, N, Ch, Chp, O, P(w), P(b), P(y), P(dp2), P(dh2), P(sc2), P(st2), C.byref(g),
+                                    halo[0], halo[1], Hc, Wc, dt, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dp1, dp2) and torch.equal(dh1, dh2)
+    # (the double partial sums are folded in a different order: equal to ~1e-15, the f32 loss to its last bit)
+    assert abs(float(sc1[0]) - float(sc2[0])) <= 1.2e-7 * abs(float(sc1[0])) and torch.allclose(st1, st2, rtol=1e-12, atol=0)
+    # and the loss against the oracle
+    hh = hsl[n0:n0 + N, Pd:Pd + H, Pd:Pd + W, :Ch].float().permute(0, 3, 1, 2).cpu()
+    po = O_.crop_pred(O_.head_forward(hh, w.cpu().view(O, Ch, 1, 1), b.cpu()), halo, (Hc, Wc))
+    lo = float(O_.loss_mse_l1(y.cpu(), po))
+    assert abs(float(sc2[0]) - lo) <= 2e-6 * abs(lo)
+    assert lib.nint_head_loss_fused(P(hsl), n0, N, Ch, 96, O, P(w), P(b), P(y), P(dp2), P(dh2), P(sc2), P(st2), C.byref(g),
+                                    halo[0], halo[1], Hc, Wc, dt, None) == -2      # NINT_E_SHAPE: wider than the fused kernel holds
+
+
 def test_adam_flat_matches_torch_golden(lib):
     g = np.load(os.path.join(GOLD, "adam.npz"))
     p = torch.from_numpy(g["p0"].copy()).cuda()

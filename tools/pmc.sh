@@ -2,7 +2,7 @@
 # Collect PMC counters for the per-kernel micro-benchmark, one rocprofv3 pass per counter group
 # (PMC runs carry --kernel-trace only).  usage: tools/pmc.sh <outdir> [kbench args...]
 set -e
-OUT=$1; shift
+OUT=$(realpath -m "$1"); shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
