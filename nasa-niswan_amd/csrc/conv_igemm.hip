@@ -63,11 +63,10 @@ extern "C" int nint_debug_read_stamps(unsigned long long* host, int n_wgs) {
 // Rounds of the K-slice exchange.  Four K-slices of a 4-row tile park 3/4 of the accumulators: in ONE round that
 // buffer (12 KiB per wave, 48 KiB) is the workgroup's whole LDS footprint for the narrow layers and caps them at 3
 // workgroups per CU; in two rounds of half the column tiles it is 24 KiB (under the halo image) and a fourth fits.
-// Measured (same device, rocprofv3): the layer-2 gate kernel -5 %; the dgrad kernels +1 % (their fourth workgroup
-// costs 12 spilled registers), so only the LSTM epilogue takes two rounds.  8-row tiles with four K-slices need four
-// rounds to stay at two workgroups per CU (96 KiB otherwise).
+// Measured (same device, rocprofv3): the layer-2 gate kernel -6 %.  8-row tiles with four K-slices need four rounds to
+// stay at two workgroups per CU (96 KiB otherwise).
 constexpr int xchg_rounds(int EPI, int WK, int NTW, int MT) {
-  return (EPI == 0 && WK == 4 && MT == 4 && NTW % 2 == 0) ? 2 : ((WK == 4 && MT == 8 && NTW == 4) ? 4 : 1);
+  return (WK == 4 && MT == 4 && NTW % 2 == 0) ? 2 : ((WK == 4 && MT == 8 && NTW == 4) ? 4 : 1);
 }
 
 template <int DT, int EPI, int WN, int WK, int NTW, int MT>
@@ -146,6 +145,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   // c_{t-1} of the rows this wave finishes in the epilogue (rows (i + wk*Q) % MT, see the K-slice exchange below).
   // 4-row tiles (the narrow layers, whose time is all memory latency) fetch it HERE, ahead of the halo fill: the loads
   // complete under the fill wait instead of stalling the epilogue on an HBM round trip (Q*NTW/4 vectors, 4-8 VGPRs).
+  // (The dgrad epilogue's read-modify-write operands stay late: held across the K loop they cost 20 registers and
+  // with them the fourth workgroup per CU.)
   // 8-row tiles have no registers to spare and fetch it at the top of the epilogue, before the first store: vmcnt
   // retires in order and counts stores too, so a load issued between the epilogue's stores would make every row wait
   // for the previous row's stores to be acknowledged (measured: 22 us of epilogue per round).
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
       }
     }
   };
-  if constexpr (EARLY) { load_cprev(); load_old(); }
+  if constexpr (EARLY) load_cprev();
   for (int c_begin = 0; c_begin < nchunks; c_begin += a.cpf) {
     const int c_cnt = min(a.cpf, nchunks - c_begin);
     if (c_begin > 0) __syncthreads();          // every wave is done reading the previous image
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   // c_{t-1} of the rows this wave finishes in the epilogue is fetched up front, before the first store: vmcnt
   // retires in order and counts stores too, so a load issued between the epilogue's stores would make every
   // row wait for the previous row's stores to be acknowledged (measured: 22 us of epilogue per round).
-  if constexpr (!EARLY) { load_cprev(); load_old(); }
+  if constexpr (!EARLY) load_cprev();
+  load_old();
   const int px = lane & 15;
   const int c4 = 4 * (lane >> 4);
   const int x = x0 + px;
