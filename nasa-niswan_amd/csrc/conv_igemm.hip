@@ -101,15 +101,34 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     const int nb = gridDim.x, b = blockIdx.x, q8 = nb / 8, r8 = nb % 8, x = b % 8, i = b / 8;
     tile = x * q8 + (x < r8 ? x : r8) + i;     // ranges of q8 (+1 for the first r8 XCDs) tiles
   }
-  const int tx = tile % a.tiles_x; tile /= a.tiles_x;
-  const int ty = tile % a.tiles_y;
-  const int img = tile / a.tiles_y;
+  // Two tile classes.  FULL tiles: MT rows x 16 pixels.  When the grid leaves 1..MT/2 rows over (100 = 12*8 + 4), the
+  // leftover strip is covered by MERGED tiles: MT/2 rows x 32 pixels, i.e. the MT row tiles of a workgroup are the
+  // rows of two adjacent 16-pixel columns.  No row tile computes padding rows, and at B = 8 the bench's gate launch
+  // is 8 * (12*10 + 5) = 1000 workgroups instead of 1040: they fit the chip's 512 slots in two rounds, without the
+  // 16-workgroup third round that kept 15 of 16 CUs idle for the last 30 us (tools/clockprobe.py).
+  const bool mg = MT >= 8 && tile >= a.n_full;                 // workgroup-uniform
+  int tx, ty, img;
+  if (!mg) {
+    tx = tile % a.tiles_x; tile /= a.tiles_x;
+    ty = tile % a.tiles_full_y;
+    img = tile / a.tiles_full_y;
+  } else {
+    tile -= a.n_full;
+    tx = tile % a.tiles_x2;
+    img = tile / a.tiles_x2;
+    ty = a.tiles_full_y;
+  }
+  constexpr int RHM = MT >= 8 ? MT / 2 : MT;                   // rows of a merged tile
   const int nt0 = a.nt_begin + blockIdx.y * NTWG + wn * NTW;   // first n-tile of this wave
-  const int y0 = ty * MT, x0 = tx * 16;
+  const int y0 = ty * MT, x0 = mg ? tx * 32 : tx * 16;
+  // row tile r of the workgroup sits at (y0 + rdy(r), x0 + rdx(r))
+  auto rdy = [&](int r) __attribute__((always_inline)) { return mg ? r % RHM : r; };
+  auto rdx = [&](int r) __attribute__((always_inline)) { return mg ? 16 * (r / RHM) : 0; };
   const int p = a.p, k = a.k, taps = a.taps;
-  const int HWt = 16 + 2 * p;                  // halo tile width
-  const int NHP = (MT + 2 * p) * HWt;          // halo tile pixels
-  const int NHPp = a.nhp_pad;                  // padded to a multiple of 16 pixels (planes stay bank aligned)
+  const int HWt = (mg ? 32 : 16) + 2 * p;      // halo tile width
+  const int NHP = ((mg ? RHM : MT) + 2 * p) * HWt;   // halo tile pixels
+  const int NHPp = mg ? a.nhp_pad2 : a.nhp_pad;      // padded to a multiple of 16 pixels (planes stay bank aligned)
+  const unsigned magic_nhpp = mg ? a.magic_nhpp2 : a.magic_nhpp, magic_hwt = mg ? a.magic_hwt2 : a.magic_hwt;
   const int plane = NHPp * 16;                 // bytes of one g-plane
   const int chunk_bytes = 4 * plane;
 
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   // K-slice exchange are then always its local rows 0..Q-1 (static register indexing)
   int rowoff[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) rowoff[i] = ((i + wk * Q) % MT) * HWt * 16;
+  for (int i = 0; i < MT; ++i) rowoff[i] = (rdy((i + wk * Q) % MT) * HWt + rdx((i + wk * Q) % MT)) * 16;
   const char* Bwave = a.Bp + (size_t)nt0 * 1024;   // wave-uniform (scalar) base; the lane part is a 32-bit offset
   const unsigned blane = lane * 16;
   const size_t bstep = (size_t)a.NTt * 1024;   // bytes between consecutive K-steps in Bp
@@ -156,7 +175,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     if constexpr (EPI == EPI_LSTM) {
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
-        const int y = y0 + (i + wk * Q) % MT, xq = x0 + (lane & 15);
+        const int r = (i + wk * Q) % MT;
+        const int y = y0 + rdy(r), xq = x0 + rdx(r) + (lane & 15);
         const float* crow = a.c_prev + ((size_t)img * a.H + y) * a.W * a.Chp;     // wave-uniform row base
 #pragma unroll
         for (int cb = 0; cb < NTW / 4; ++cb) {
@@ -173,10 +193,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   auto load_old = [&]() __attribute__((always_inline)) {
     if constexpr (HOIST) {
       const bool rmw = a.out0 && !a.out0_overwrite;
-      const int c4 = 4 * (lane >> 4), x = x0 + (lane & 15);
+      const int c4 = 4 * (lane >> 4);
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
-        const int y = y0 + (i + wk * Q) % MT;
+        const int r = (i + wk * Q) % MT;
+        const int y = y0 + rdy(r), x = x0 + rdx(r) + (lane & 15);
         const size_t rowpix = ((size_t)img * a.H + y) * a.W;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -202,11 +223,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
       const int u = ub + lane;
       // u / NHPp and hp / HWt by multiply-high with host-side magic numbers (exact for u < 65536, divisor <= 4096):
       // an integer division by a run-time value costs ~25 VALU instructions, and there are two per unit
-      const int cq = (int)__umulhi((unsigned)u, a.magic_nhpp);   // cl*4 + q
+      const int cq = (int)__umulhi((unsigned)u, magic_nhpp);   // cl*4 + q
       int hp = u - cq * NHPp;
       hp = hp < NHP ? hp : 0;
       const int q = cq & 3, cl = cq >> 2;
-      const int hy = (int)__umulhi((unsigned)hp, a.magic_hwt);
+      const int hy = (int)__umulhi((unsigned)hp, magic_hwt);
       const int hx = hp - hy * HWt;
       const int c = c_begin + cl;
       const char* src = (c < a.nchunk0)
@@ -422,9 +443,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
       const unsigned lo_g = (unsigned)(x * Gc + cblock * 64) + (DT == NINT_BF16 ? (unsigned)(chb + (odd ? 32 : 0)) : (unsigned)c4);
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
-        const int y = y0 + (i + wk * Q) % MT;
-        const bool ok = y < a.H && x < a.W;      // (the lane exchange below needs every lane: no divergent block)
-        const size_t rowpix = ((size_t)img * a.H + y) * a.W;
+        const int rt = (i + wk * Q) % MT;        // row tile of the workgroup
+        const int y = y0 + rdy(rt), xo = rdx(rt);
+        const bool ok = y < a.H && x + xo < a.W; // (the lane exchange below needs every lane: no divergent block)
+        const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;   // (a merged tile's second column: 16 pixels on)
         const f32x4_t cp = cpv[i][cb];
         f32x4_t gi, gf, gg, go, cn, hn;
 #pragma unroll
@@ -438,7 +460,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
         }
         if (ok) {
           *(f32x4_t*)(a.c_out + rowpix * a.Chp + lo_c) = cn;
-          char* hrow = a.h_out + (((size_t)img * a.Hh + (y + a.P)) * a.Wh) * a.Chp * Elem<DT>::ES;
+          char* hrow = a.h_out + (((size_t)img * a.Hh + (y + a.P)) * a.Wh + xo) * a.Chp * Elem<DT>::ES;
           store_vec4<DT>(hrow, lo_h, hn);
         }
         if (a.gates_out) {
@@ -476,9 +498,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     const bool rmw = a.out0 && !a.out0_overwrite;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
-      const int y = y0 + (i + wk * Q) % MT;
-      if (y < a.H && x < a.W) {
-        const size_t rowpix = ((size_t)img * a.H + y) * a.W;
+      const int rt = (i + wk * Q) % MT;
+      const int y = y0 + rdy(rt), xo = rdx(rt);
+      if (y < a.H && x + xo < a.W) {
+        const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           const int n = (nt0 + j) * 16 + c4;
@@ -508,7 +531,23 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   a.nhp_pad = nint_round_up(NHP, 16);
   a.magic_nhpp = (unsigned)(((1ull << 32) + a.nhp_pad - 1) / a.nhp_pad);
   a.magic_hwt = (unsigned)(((1ull << 32) + (16 + 2 * a.p) - 1) / (16 + 2 * a.p));
-  const int chunk_bytes = 4 * a.nhp_pad * 16;
+  a.tiles_x = nint_cdiv(a.W, 16);
+  a.tiles_y = nint_cdiv(a.H, MT);
+  // leftover strip of 1..MT/2 rows (8-row tiles): merged tiles of MT/2 rows x 32 pixels instead of half-empty ones
+  const int left = a.H % MT;
+  const bool merge = MT >= 8 && left >= 1 && left <= MT / 2 && a.tiles_x >= 2;
+  a.tiles_full_y = merge ? a.H / MT : a.tiles_y;
+  a.tiles_x2 = merge ? nint_cdiv(a.tiles_x, 2) : 0;
+  a.n_full = N * a.tiles_x * a.tiles_full_y;
+  int nhp_max = a.nhp_pad;
+  if (merge) {
+    const int NHP2 = (MT / 2 + 2 * a.p) * (32 + 2 * a.p);
+    a.nhp_pad2 = nint_round_up(NHP2, 16);
+    a.magic_nhpp2 = (unsigned)(((1ull << 32) + a.nhp_pad2 - 1) / a.nhp_pad2);
+    a.magic_hwt2 = (unsigned)(((1ull << 32) + (32 + 2 * a.p) - 1) / (32 + 2 * a.p));
+    if (a.nhp_pad2 > nhp_max) nhp_max = a.nhp_pad2;
+  }
+  const int chunk_bytes = 4 * nhp_max * 16;    // (the larger of the two tile images)
   const int nchunks = a.nchunk0 + a.nchunk1;
   const int red_bytes = WK > 1 ? WN * WK * (MT - MT / WK) * (NTW / xchg_rounds(EPI, WK, NTW, MT)) * 1024 : 0;   // K-slice exchange buffer
   // as many channel chunks per fill as fit in ~72 KiB (two workgroups per CU stay resident)
@@ -523,12 +562,10 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   size_t lds = (size_t)a.a_bytes;
   if ((size_t)red_bytes > lds) lds = red_bytes;
   if (lds > 160 * 1024) return NINT_E_LDS;
-  a.tiles_x = nint_cdiv(a.W, 16);
-  a.tiles_y = nint_cdiv(a.H, MT);
   auto kern = conv_igemm_kernel<DT, EPI, WN, WK, NTW, MT>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid(a.tiles_x * a.tiles_y * N, ngroups_y), block(256);
+  dim3 grid(a.n_full + N * a.tiles_x2, ngroups_y), block(256);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
@@ -540,7 +577,10 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   // short-K launches (narrow layers) take 4-row tiles; nint_layer.tile_rows = 4 | 8 overrides (tests run both
   // heights on every shape)
   const int ksteps = a.nchunk0 * a.k * a.kx0 + a.nchunk1 * a.taps;
-  const bool mt4 = a.tile_rows ? a.tile_rows == 4 : (ksteps <= 48 || ntiles <= 4);
+  // (measured with the leftover strip merged, B = 8, 100x154: dgrad layer 0 -- 200 steps, 4 column tiles -- 94.7 us with
+  // 8-row tiles against 104.0; dgrad layer 1 -- 36 steps -- 40.2 against 41.5; the 18-27-step launches prefer 4 rows)
+  const bool mt4 = a.tile_rows ? a.tile_rows == 4
+                               : (EPI == EPI_DGRAD ? ksteps <= 32 : (ksteps <= 48 || ntiles <= 4));
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;

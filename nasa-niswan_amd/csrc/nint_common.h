@@ -123,6 +123,9 @@ struct ConvArgs {
   int kx0;               // horizontal taps of src0: k, or 1 for a horizontally folded x source (nint_layer.xfold)
   int H, W, P, Hh, Wh;
   int tiles_x, tiles_y;
+  int tiles_full_y, tiles_x2, n_full;   // full tile rows, merged tiles per image (0: none), number of full tiles in the launch
+  int nhp_pad2;                         // halo-tile pixels of a merged tile (MT/2 rows x 32 pixels), rounded up to 16
+  unsigned magic_nhpp2, magic_hwt2;
   int tile_rows;         // 0 = per launch shape, 4 / 8 = forced tile height
 #ifdef NINT_EXPERIMENT
   int dbg;               // experiment build only: tile-configuration selector (upper bits of nint_layer.tile_rows)
