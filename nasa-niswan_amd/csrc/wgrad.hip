@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   constexpr int b_bytes = NB_U_PAD * 16;
   constexpr int buf_bytes = a_bytes + b_bytes;
   static_assert(NA_U % 64 == 0 && a_bytes % 1024 == 0, "whole DMA pieces");
-  constexpr int NI_A = NA_U / 64, NI_B = NB_U_PAD / 64, NI = NI_A + NI_B, NI_W = (NI + 3) / 4;
+  constexpr int NI_A = NA_U / 64, NI_B = NB_U_PAD / 64, NI = NI_A + NI_B;
 
   const int nb = blockIdx.y / a.CB, cb = blockIdx.y % a.CB;
   const int t_begin = blockIdx.x * a.tiles_per_split;
@@ -78,12 +78,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < JW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // Per-lane source offsets of this wave's DMA pieces (piece t = wave + 4*i), relative to the wave-uniform tile
-  // base: they do not depend on the tile, so the tile loop spends no VALU on staging addresses.
-  unsigned doff[NI_W];
+  // DMA pieces of a tile are dealt to the waves in CONTIGUOUS ranges sized to even out each wave's work per tile:
+  // a wave with fewer real columns (25 taps over 4 waves = 7, 7, 7, 4) has idle issue slots that the staging of the
+  // next tile can use, so it takes more pieces: n_w = (L - nv_w * CM) / CD with the common level L such that the n_w
+  // sum to NI (CM = matrix-pipe cycles per column and tile, CD ~ issue cost of one piece).  Wave-uniform integer math.
+  constexpr int NI_WM = (NI + 1) / 2;                    // most pieces one wave may take
+  int p_begin, p_cnt;
+  {
+    constexpr int CM = (DT == NINT_BF16 ? 16 : 32 * 4) * NTN * PR, CD = 100;
+    int nv[4], n16[4], tot = 0, sum_nv = 0;
 #pragma unroll
-  for (int i = 0; i < NI_W; ++i) {
-    const int t = wave + 4 * i;
+    for (int w = 0; w < 4; ++w) { nv[w] = min(JW, max(0, a.J - (w / NS) * JW)); sum_nv += nv[w]; }
+    const int L = (NI * CD + CM * sum_nv) / 4;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { n16[w] = max(0, (L - nv[w] * CM) * 16 / CD); tot += n16[w]; }
+    // scale to NI pieces (rounded prefix sums), cap every wave at NI_WM and hand the excess on (4 * NI_WM >= 2 * NI)
+    int cnt[4], prev = 0, acc16 = 0, excess = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      acc16 += n16[w];
+      const int e = w == 3 ? NI : (tot > 0 ? min(NI, (acc16 * NI + tot / 2) / tot) : (w + 1) * NI / 4);
+      cnt[w] = e - prev;
+      prev = e;
+      if (cnt[w] > NI_WM) { excess += cnt[w] - NI_WM; cnt[w] = NI_WM; }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int take = min(NI_WM - cnt[w], excess);
+      cnt[w] += take;
+      excess -= take;
+    }
+    const int s1 = cnt[0], s2 = s1 + cnt[1], s3 = s2 + cnt[2];
+    p_begin = wave == 0 ? 0 : (wave == 1 ? s1 : (wave == 2 ? s2 : s3));
+    p_cnt = wave == 0 ? cnt[0] : (wave == 1 ? cnt[1] : (wave == 2 ? cnt[2] : cnt[3]));
+  }
+  // Per-lane source offsets of this wave's DMA pieces (piece t = p_begin + i), relative to the wave-uniform tile
+  // base: they do not depend on the tile, so the tile loop spends no VALU on staging addresses.
+  unsigned doff[NI_WM];
+#pragma unroll
+  for (int i = 0; i < NI_WM; ++i) {
+    const int t = p_begin + i;
     unsigned o = 0;
     if (t < NI_A) {
       const int u = t * 64 + lane;
@@ -113,9 +147,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const char* ga = ga0 + (long)ld_img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride;
     const char* gb = gb0 + (long)ld_img * a.src_img_stride + ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride;
 #pragma unroll
-    for (int i = 0; i < NI_W; ++i) {
-      const int t = wave + 4 * i;              // wave-uniform
-      if (t < NI) {
+    for (int i = 0; i < NI_WM; ++i) {
+      const int t = p_begin + i;               // wave-uniform
+      if (i < p_cnt) {
         const char* src = (t < NI_A ? ga : gb) + doff[i];
         char* dst = buf + (t < NI_A ? t * 1024 : a_bytes + (t - NI_A) * 1024);
         // issued as inline asm ON PURPOSE: hipcc would count the builtin as an LDS write and wait vmcnt(0) ahead
