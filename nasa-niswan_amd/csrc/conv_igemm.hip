@@ -84,15 +84,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wk = wave / WN;
-#ifdef NINT_EXPERIMENT
-  // stagger experiment: the first-dispatched workgroups (one per resident slot) start in 2..4 phase groups, dbg%10 us apart
-  if (a.dbg >= 20 && blockIdx.y == 0) {
-    const int ngrp = a.dbg / 10, us = a.dbg % 10;
-    const int grp = (blockIdx.x >> 8) % ngrp;
-    if ((int)blockIdx.x < 256 * 4)
-      for (int i = 0; i < grp * us; ++i) __builtin_amdgcn_s_sleep(32);     // ~1 us each
-  }
-#endif
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
   // with its own L2, so XCD x takes the CONTIGUOUS tile range x: neighbouring tiles (which share halo
   // pixels) and, at B = 8, whole images then stay inside one L2.  Any bijection is correct.
