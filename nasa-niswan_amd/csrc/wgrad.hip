@@ -16,6 +16,7 @@
 // Each workgroup keeps its 64 x (16*NTC*taps) output block in accumulators for its whole pixel
 // range and writes ONE partial slab; a second kernel folds the slabs in fixed order
 // (bitwise reproducible, no float atomics) into the OIHW gradient.
+#include <type_traits>
 #include "nint_common.h"
 
 struct WgradArgs {
@@ -204,63 +205,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       vB[jj] = a_bytes + (tyy * HWt + txx + g) * RB + (ct * 16 + i16) * 4;
     }
   }
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int cur = (tile - t_begin) & 1;
-    const bool more = tile + 1 < t_end;
-    if (more) issue_dma(smem + (cur ^ 1) * buf_bytes);   // the other buffer was last read before the previous barrier
-    const char* Ab = smem + cur * buf_bytes + vA;      // one add per base and tile; everything below is base + immediate
-    const char* Bb[JW];
+  // The tile loop exists once per column count a wave can have (JW, the NVL columns left for the last group, or none):
+  // inside it the column count is a compile-time constant, so a tile is ONE basic block -- the compiler is free to
+  // hoist the transposed reads of pixel row pr+1 above the MFMAs of row pr -- and no MFMA is predicated.  Every variant
+  // issues the same DMA pieces and the same barriers.
+  auto run_tiles = [&](auto nvc) __attribute__((always_inline)) {
+    constexpr int NV = decltype(nvc)::value;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int cur = (tile - t_begin) & 1;
+      const bool more = tile + 1 < t_end;
+      if (more) issue_dma(smem + (cur ^ 1) * buf_bytes);   // the other buffer was last read before the previous barrier
+      const char* Ab = smem + cur * buf_bytes + vA;      // one add per base and tile; everything below is base + immediate
+      const char* Bb[JW];
 #pragma unroll
-    for (int jj = 0; jj < JW; ++jj) Bb[jj] = smem + cur * buf_bytes + vB[jj];
-    if constexpr (DT == NINT_BF16) {
+      for (int jj = 0; jj < JW; ++jj) Bb[jj] = smem + cur * buf_bytes + vB[jj];
+      if constexpr (NV > 0 && DT == NINT_BF16) {
 #pragma unroll
-      for (int pr = 0; pr < PR; ++pr) {
-        // pixel -> K-slot: read rd covers pixels rd*16 + 4*g + q of the 32-pixel row segment.  (Double-buffering
-        // the fragments per pixel row -- reads of row pr+1 ahead of the MFMAs of row pr -- was measured: it gives
-        // back what the LDS-DMA staging gained, 236 VGPRs.)
-        auto read_tr = [&](const char* ad, int half) __attribute__((always_inline)) {
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + half));
-          u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-          return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
-        };
-        u32x4_t af[NTN], bf[JW];
+        for (int pr = 0; pr < PR; ++pr) {
+          // pixel -> K-slot: read rd covers pixels rd*16 + 4*g + q of the 32-pixel row segment
+          auto read_tr = [&](const char* ad, int half) __attribute__((always_inline)) {
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + half));
+            u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+            return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
+          };
+          u32x4_t af[NTN], bf[NV];
 #pragma unroll
-        for (int i = 0; i < NTN; ++i) af[i] = read_tr(Ab + pr * 32 * RA + i * 32, 16 * RA);
+          for (int i = 0; i < NTN; ++i) af[i] = read_tr(Ab + pr * 32 * RA + i * 32, 16 * RA);
 #pragma unroll
-        for (int jj = 0; jj < JW; ++jj) bf[jj] = read_tr(Bb[jj] + pr * HWt * RB, 16 * RB);
-        // The reads are unconditional (clamped columns).  A wave has JW, NVL (= the columns left for the last
-        // group) or 0 real columns, so two wave-uniform branches per pixel row cover every case -- one per column
-        // would cost 2 SALU instructions each -- and every MFMA still appears exactly once in the code.
-        if (nvalid > 0) {
+          for (int jj = 0; jj < NV; ++jj) bf[jj] = read_tr(Bb[jj] + pr * HWt * RB, 16 * RB);
 #pragma unroll
-          for (int jj = 0; jj < NVL; ++jj)
-#pragma unroll
-            for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
-        }
-        if (nvalid == JW) {
-#pragma unroll
-          for (int jj = NVL; jj < JW; ++jj)
+          for (int jj = 0; jj < NV; ++jj)
 #pragma unroll
             for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
         }
-      }
-    } else {
+      } else if constexpr (NV > 0) {
 #pragma unroll
-      for (int pr = 0; pr < PR; ++pr) {
+        for (int pr = 0; pr < PR; ++pr) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          // 16 pixels per K-step: MFMA m takes pixel 4*m + g of the segment as its K index g
+          for (int ks = 0; ks < 2; ++ks) {
+            // 16 pixels per K-step: MFMA m takes pixel 4*m + g of the segment as its K index g
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            float af[NTN];
+            for (int m = 0; m < 4; ++m) {
+              float af[NTN];
 #pragma unroll
-            for (int i = 0; i < NTN; ++i)
-              af[i] = *(const float*)(Ab + (pr * 32 + ks * 16 + 4 * m) * RA + i * 64);
+              for (int i = 0; i < NTN; ++i)
+                af[i] = *(const float*)(Ab + (pr * 32 + ks * 16 + 4 * m) * RA + i * 64);
 #pragma unroll
-            for (int jj = 0; jj < JW; ++jj) {
-              const float bf = *(const float*)(Bb[jj] + (pr * HWt + ks * 16 + 4 * m) * RB);
-              if (jj < nvalid) {
+              for (int jj = 0; jj < NV; ++jj) {
+                const float bf = *(const float*)(Bb[jj] + (pr * HWt + ks * 16 + 4 * m) * RB);
 #pragma unroll
                 for (int i = 0; i < NTN; ++i)
                   acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
@@ -269,10 +262,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
           }
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed ...
+      __syncthreads();                           // ... for every wave, and this one is fully read
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed ...
-    __syncthreads();                           // ... for every wave, and this one is fully read
-  }
+  };
+  if (nvalid == JW) run_tiles(std::integral_constant<int, JW>{});
+  else if (nvalid == NVL) run_tiles(std::integral_constant<int, NVL>{});
+  else run_tiles(std::integral_constant<int, 0>{});      // a wave without real columns only stages and synchronises
 
   // ---- flush: partial[split][blockIdx.y][j][n'loc 64][c 16]
   float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * a.J * 1024;
