@@ -23,7 +23,8 @@ struct WgradArgs {
   const char* dG; long dG_img_stride; int dG_pix_stride;
   const char* src; long src_img_stride; int src_pix_stride;
   float* partial;
-  int CB, NTC, J;
+  int CB, NTC, J;        // channel blocks, channel tiles per block, (tap, channel-tile) columns in all
+  int TG, JG;            // column groups of 4*JW columns (49 taps of a 7x7 kernel: 2) and columns per block slab
   int k, p, taps;
   int P, Wh;
   int tiles_x, tiles_y, ntiles, tiles_per_split;
@@ -67,7 +68,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   static_assert(NA_U % 64 == 0 && a_bytes % 1024 == 0, "whole DMA pieces");
   constexpr int NI_A = NA_U / 64, NI_B = NB_U_PAD / 64, NI = NI_A + NI_B;
 
-  const int nb = blockIdx.y / a.CB, cb = blockIdx.y % a.CB;
+  // (integer division runs on the vector ALU: readfirstlane puts the workgroup-uniform results back into scalars)
+  const int tg = __builtin_amdgcn_readfirstlane(blockIdx.y % a.TG);   // column group
+  const int bc = __builtin_amdgcn_readfirstlane(blockIdx.y / a.TG);   // (gate block, channel block)
+  const int nb = bc / a.CB, cb = bc % a.CB;
+  const int jb = tg * 4 * JW;                 // first column of this workgroup
   const int t_begin = blockIdx.x * a.tiles_per_split;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
   const int i0 = (wave % NS) * NTN;           // first row tile (16 gate columns each) of this wave
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     constexpr int CM = (DT == NINT_BF16 ? 16 : 32 * 4) * NTN * PR, CD = 100;
     int nv[4], n16[4], tot = 0, sum_nv = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { nv[w] = min(JW, max(0, a.J - (w / NS) * JW)); sum_nv += nv[w]; }
+    for (int w = 0; w < 4; ++w) { nv[w] = min(JW, max(0, a.J - jb - (w / NS) * JW)); sum_nv += nv[w]; }
     const int L = (NI * CD + CM * sum_nv) / 4;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { n16[w] = max(0, (L - nv[w] * CM) * 16 / CD); tot += n16[w]; }
@@ -110,8 +115,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       excess -= take;
     }
     const int s1 = cnt[0], s2 = s1 + cnt[1], s3 = s2 + cnt[2];
-    p_begin = wave == 0 ? 0 : (wave == 1 ? s1 : (wave == 2 ? s2 : s3));
-    p_cnt = wave == 0 ? cnt[0] : (wave == 1 ? cnt[1] : (wave == 2 ? cnt[2] : cnt[3]));
+    // (the divisions above run on the vector ALU: back into scalars, the LDS destination of a DMA piece is an SGPR)
+    p_begin = __builtin_amdgcn_readfirstlane(wave == 0 ? 0 : (wave == 1 ? s1 : (wave == 2 ? s2 : s3)));
+    p_cnt = __builtin_amdgcn_readfirstlane(wave == 0 ? cnt[0] : (wave == 1 ? cnt[1] : (wave == 2 ? cnt[2] : cnt[3])));
   }
   // Per-lane source offsets of this wave's DMA pieces (piece t = p_begin + i), relative to the wave-uniform tile
   // base: they do not depend on the tile, so the tile loop spends no VALU on staging addresses.
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         // DMA is invisible to its bookkeeping, so the wait is ours: s_waitcnt vmcnt(0) ahead of the tile's barrier.
         // (M0 = LDS destination base; saved and restored in the same statement.)
         unsigned keep;
-        const unsigned lds_dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dst);
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
       }
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   // the K loop branch-free.
   int vB[JW];
   int vA;
-  const int nvalid = __builtin_amdgcn_readfirstlane(min(JW, max(0, a.J - j0)));   // real columns of this wave
+  const int nvalid = __builtin_amdgcn_readfirstlane(min(JW, max(0, a.J - jb - j0)));   // real columns of this wave
   constexpr int JT = KS * KX * NTCT;                                              // = a.J (host-checked)
   constexpr int XO = KX == KS ? 0 : p;                                            // folded: the centre column
   constexpr int NVL = JT % JW == 0 ? JW : JT % JW;                                // columns of the last, partial group
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     vA = (4 * g + q) * RA + i0 * 32 + p8;             // pixel 4g+q of a 16-pixel half segment, 8 bytes of 4 channels
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
-      const int j = min(j0 + jj, a.J - 1);
+      const int j = min(jb + j0 + jj, a.J - 1);
       const int tap = j / NTCT, ct = j - tap * NTCT;
       const int tyy = tap / KX, txx = tap - tyy * KX + XO;
       vB[jj] = a_bytes + (tyy * HWt + txx + 4 * g + q) * RB + ct * 32 + p8;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     vA = g * RA + (i0 * 16 + i16) * 4;                // MFMA m of a 16-pixel K-step takes pixel 4m+g
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
-      const int j = min(j0 + jj, a.J - 1);
+      const int j = min(jb + j0 + jj, a.J - 1);
       const int tap = j / NTCT, ct = j - tap * NTCT;
       const int tyy = tap / KX, txx = tap - tyy * KX + XO;
       vB[jj] = a_bytes + (tyy * HWt + txx + g) * RB + (ct * 16 + i16) * 4;
@@ -270,12 +276,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   else if (nvalid == NVL) run_tiles(std::integral_constant<int, NVL>{});
   else run_tiles(std::integral_constant<int, 0>{});      // a wave without real columns only stages and synchronises
 
-  // ---- flush: partial[split][blockIdx.y][j][n'loc 64][c 16]
-  float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * a.J * 1024;
+  // ---- flush: partial[split][blockIdx.y][j local][n'loc 64][c 16]
+  float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * a.JG * 1024;
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) {
     const int j = j0 + jj;
-    if (j < a.J) {
+    if (jb + j < a.J) {
 #pragma unroll
       for (int i = 0; i < NTN; ++i)
 #pragma unroll
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 struct ReduceEntry {
   const float* part; float* dW;
   int Cx, Ch, Ch16, k, NB, CB, NTC, J, splits, is_h, xfold;
+  int TG, JG;                               // column groups per block column, columns per block slab
   int waves;                                // waves that share the splits of one 64-element line (the others exit)
   unsigned blk_begin;                       // first workgroup of this (layer, source) in the merged launch
 };
@@ -303,10 +310,11 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   for (int q = 1; q < t.n; ++q) ei = blockIdx.x >= t.e[q].blk_begin ? q : ei;     // entries are in launch order
   const ReduceEntry& E = t.e[ei];
   const int Cx = E.Cx, Ch = E.Ch, k = E.k, CB = E.CB, NTC = E.NTC, J = E.J, splits = E.splits, is_h = E.is_h;
+  const int TG = E.TG, JG = E.JG;
   const float* __restrict__ part = E.part;
   float* __restrict__ dW = E.dW;
   const int taps = k * k, Ctot = Cx + Ch;
-  const size_t slab = (size_t)E.NB * CB * J * 1024;
+  const size_t slab = (size_t)E.NB * CB * TG * JG * 1024;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, G = E.waves;   // waves >= G idle through the barrier
   const size_t i = (size_t)(blockIdx.x - E.blk_begin) * 64 + lane;       // slab is a multiple of 1024: no tail
   float s = 0.f;
@@ -320,9 +328,12 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   for (int q = 1; q < G; ++q) s += red[q * 64 + lane];
   const int c16 = i & 15, nloc = (i >> 4) & 63;
   size_t r = i >> 10;
-  const int j = r % J; r /= J;
+  const int jl = r % JG; r /= JG;
+  const int tgi = r % TG; r /= TG;
   const int cb = r % CB;
   const int nb = r / CB;
+  const int j = tgi * JG + jl;
+  if (j >= J) return;                                 // unused slots of the last column group
   int tap = j / NTC;
   const int ct = j - tap * NTC;
   int cc = (cb * NTC + ct) * 16 + c16;                // channel inside this source
@@ -407,7 +418,7 @@ __global__ void colsum_final_kernel(BiasTable t, int nrows) {
 }
 
 // ------------------------------------------------------------------------------ host side
-struct WgPart { int NTC, J, JW, KX, CB, splits; };   // one source (x or h) of the reduction
+struct WgPart { int NTC, J, JW, KX, CB, TG, JG, splits; };   // one source (x or h) of the reduction
 struct WgPlan {
   WgPart part[2];
   int NB, tiles_x, tiles_y, ntiles;
@@ -416,7 +427,7 @@ struct WgPlan {
 };
 
 static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_geom* g, WgPlan* pl) {
-  if (ly->k != 1 && ly->k != 3 && ly->k != 5) return NINT_E_SHAPE;
+  if (ly->k != 1 && ly->k != 3 && ly->k != 5 && ly->k != 7) return NINT_E_SHAPE;
   pl->NB = 4 * ly->Ch16 / 64;
   const int PR = dtype == NINT_BF16 ? 4 : 2;
   pl->tiles_x = g ? nint_cdiv(g->W, 32) : 1;
@@ -433,18 +444,22 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
     w.J = taps * w.NTC;
     // every wave owns all 4 row tiles (64 gate columns) and a quarter of the (tap, channel-tile) columns
     w.JW = w.J <= 20 ? 5 : 7;
-    if (w.J > 4 * w.JW) return NINT_E_SHAPE;
+    // more than 4*JW columns (the 49 taps of a 7x7 kernel): column groups on extra workgroups; only whole waves of
+    // columns there (the tile loop exists for JW, J % JW and 0 columns per wave)
+    w.TG = nint_cdiv(w.J, 4 * w.JW);
+    w.JG = w.TG == 1 ? w.J : 4 * w.JW;
+    if (w.TG > 1 && w.J % w.JW) return NINT_E_SHAPE;
     const int CW = 16 * w.NTC;
     if (Cp % CW) return NINT_E_SHAPE;
     w.CB = Cp / CW;
     // two workgroups per CU in flight, but never fewer than 32 pixel tiles per split: the
     // accumulator flush (J KiB-tiles per workgroup) must stay small against the K work
-    int s = nint_cdiv(2 * n_cu, pl->NB * w.CB);
+    int s = nint_cdiv(2 * n_cu, pl->NB * w.CB * w.TG);
     if (s > pl->ntiles / 32) s = pl->ntiles / 32;
     if (s < 1) s = 1;
     // re-derive the split count so that no split is empty
     w.splits = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
-    floats[q] = (size_t)w.splits * pl->NB * w.CB * w.J * 1024;
+    floats[q] = (size_t)w.splits * pl->NB * w.CB * w.TG * w.JG * 1024;
   }
   pl->db_rows = 64;
   pl->off_h = floats[0];
@@ -493,6 +508,10 @@ static int dispatch_wgrad(WgradArgs& a, const WgPart& w, int nblk, hipStream_t s
     case 5 * 1000 + 1 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 5, 1, 1>(a, w.splits, nblk, st);
     case 3 * 1000 + 2 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 3, 2, 1>(a, w.splits, nblk, st);
     case 3 * 1000 + 1 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 3, 1, 1>(a, w.splits, nblk, st);
+    // 7x7 kernels: 49 taps in two column groups; folded thin inputs 7 or 14 columns
+    case 7 * 1000 + 1 * 100 + 7 * 10 + 7: return launch_wgrad<DT, 7, 7, 1, 7>(a, w.splits, nblk, st);
+    case 7 * 1000 + 2 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 7, 2, 1>(a, w.splits, nblk, st);
+    case 7 * 1000 + 1 * 100 + 5 * 10 + 1: return launch_wgrad<DT, 5, 7, 1, 1>(a, w.splits, nblk, st);
     default: return NINT_E_SHAPE;
   }
 }
@@ -540,21 +559,21 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       a.src = (const char*)(part == 0 ? jb.x_slab : jb.h_slab) + (size_t)skip * a.src_img_stride;
       a.partial = base + (part == 0 ? 0 : pl.off_h);
       a.CB = w.CB;
-      a.NTC = w.NTC; a.J = w.J;
+      a.NTC = w.NTC; a.J = w.J; a.TG = w.TG; a.JG = w.JG;
       a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * w.KX;
       a.P = g->P; a.Wh = g->Wh;
       a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
       a.ntiles = (jb.N - skip) * pl.tiles_x * pl.tiles_y;  // empty splits flush zeros
       a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
-      const int nblk = pl.NB * a.CB;
+      const int nblk = pl.NB * a.CB * w.TG;
       rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);
       if (rc != NINT_OK) return rc;
       ReduceEntry& E = rt.e[rt.n++];
       E.part = a.partial; E.dW = jb.dW;
       E.Cx = ly->Cx; E.Ch = ly->Ch; E.Ch16 = ly->Ch16; E.k = ly->k; E.NB = pl.NB; E.CB = w.CB; E.NTC = w.NTC; E.J = w.J;
-      E.splits = w.splits; E.is_h = part; E.xfold = ly->xfold;
+      E.splits = w.splits; E.is_h = part; E.xfold = ly->xfold; E.TG = w.TG; E.JG = w.JG;
       E.blk_begin = blk;
-      blk += (unsigned)((size_t)pl.NB * w.CB * w.J * 1024 / 64);
+      blk += (unsigned)((size_t)pl.NB * w.CB * w.TG * w.JG * 1024 / 64);
       E.waves = w.splits >= 64 ? 16 : 4;         // few large slabs: 4 waves share the splits; many small slabs: 16 waves
       if (E.waves * 64 > red_threads) red_threads = E.waves * 64;
     }

@@ -182,7 +182,7 @@ class SeqEngine:
     @staticmethod
     def untrainable_layers(cfgs: Sequence[LayerCfg], dtype, n_cu: int = 256) -> List[str]:
         """Layers whose weight gradient no kernel instantiation covers (`nint_wgrad_workspace_bytes` == 0):
-        kernel sizes other than 1, 3, 5, or more (tap, channel-tile) columns than one workgroup holds.  Pure host
+        kernel sizes other than 1, 3, 5, 7.  Pure host
         arithmetic -- callable without a GPU."""
         lib = _lib.load()
         dt = dtype_code(dtype)
@@ -200,7 +200,7 @@ class SeqEngine:
     def acquire(self, B, T, H, W, train: bool, has_init: bool) -> Workspace:
         if train and self.train_unsupported:
             raise _lib.NintError("training is not supported for " + ", ".join(self.train_unsupported) + ": the weight-gradient "
-                                 "kernel is instantiated for kernel sizes 1, 3 and 5 only (the reference accepts any odd k, "
+                                 "kernel is instantiated for kernel sizes 1, 3, 5 and 7 only (the reference accepts any odd k, "
                                  "model.py:204); forward / inference (torch.no_grad()) work for every odd k")
         key = (B, T, H, W, train, has_init)
         for ws in self.pool.setdefault(key, []):

@@ -63,7 +63,9 @@ def test_geometry_and_workspace_queries_are_host_only():
     ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k = 5, 32, 64, 64, 64, 5
     assert lib.nint_wgrad_workspace_bytes(C.byref(ly), 1, 256) > 0
     ly.k = 7
-    assert lib.nint_wgrad_workspace_bytes(C.byref(ly), 1, 256) == 0   # k=7 not instantiated
+    assert lib.nint_wgrad_workspace_bytes(C.byref(ly), 1, 256) > 0    # 49 taps in two column groups
+    ly.k = 9
+    assert lib.nint_wgrad_workspace_bytes(C.byref(ly), 1, 256) == 0   # k=9 not instantiated
 
 
 def test_product_refuses_cpu_tensors():
@@ -125,13 +127,13 @@ def test_modules_pickle_and_deepcopy_without_their_engines():
 
 
 def test_untrainable_kernel_sizes_are_known_before_any_backward():
-    """The reference accepts any odd k (model.py:204); the weight-gradient kernel is instantiated for 1, 3, 5.
+    """The reference accepts any odd k (model.py:204); the weight-gradient kernel is instantiated for 1, 3, 5, 7.
     The engine learns that from the library at construction (pure host arithmetic, no GPU) and refuses a TRAINING
     workspace with a message that names the layer, instead of a generic shape error in the first backward()."""
     from nasa_niswan_amd.engine import LayerCfg, SeqEngine
-    assert SeqEngine.untrainable_layers([LayerCfg(5, 64, 5), LayerCfg(64, 32, 3), LayerCfg(32, 16, 1)], "bf16") == []
-    bad = SeqEngine.untrainable_layers([LayerCfg(5, 16, 3), LayerCfg(16, 8, 7)], "f32")
-    assert len(bad) == 1 and "layer 1" in bad[0] and "k=7" in bad[0]
+    assert SeqEngine.untrainable_layers([LayerCfg(5, 64, 5), LayerCfg(64, 32, 3), LayerCfg(32, 16, 1), LayerCfg(16, 8, 7)], "bf16") == []
+    bad = SeqEngine.untrainable_layers([LayerCfg(5, 16, 3), LayerCfg(16, 8, 9)], "f32")
+    assert len(bad) == 1 and "layer 1" in bad[0] and "k=9" in bad[0]
 
 
 def test_library_reads_no_environment_and_owns_no_streams():

@@ -144,18 +144,26 @@ def test_heavy_tail_inputs(pkg, dtype):
     check(res, dtype)
 
 
-def test_k7_forward_works_and_training_is_refused_early(pkg):
-    """The reference accepts any odd kernel size (padding k//2, model.py:204).  The gate kernel is generic in k; the
-    weight-gradient kernel is instantiated for k = 1, 3, 5 -- so a k=7 model runs forward / inference and is refused
-    a TRAINING workspace with a NintError naming the layer (not a shape error out of the first backward())."""
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_k7_trains(pkg, dtype):
+    """The reference accepts any odd kernel size (padding k//2, model.py:204).  7x7: the weight gradient's 49 taps run as
+    two column groups; a thin 3-channel input is folded (7 x 21 channels), a 16-channel one is not."""
+    check(run_case(pkg, 3, [8, 8], [7, 7], 1, 2, 2, 12, 20, dtype, seed=7), dtype)
+    check(run_case(pkg, 16, [16], [7], 2, 1, 2, 9, 37, dtype, seed=8), dtype)
+
+
+def test_k9_forward_works_and_training_is_refused_early(pkg):
+    """The gate kernel is generic in k; the weight-gradient kernel is instantiated for k = 1, 3, 5, 7 -- so a k=9 model
+    runs forward / inference and is refused a TRAINING workspace with a NintError naming the layer (not a shape error
+    out of the first backward())."""
     from oracle import convlstm_oracle as O
-    params = O.synth_params(3, [8], [7], 1, seed=7)
+    params = O.synth_params(3, [8], [9], 1, seed=7)
     rng = np.random.default_rng(7)
     X = torch.from_numpy(rng.standard_normal((2, 2, 3, 12, 20)).astype(np.float32))
-    net = pkg.ConvLSTM(3, [8], [7], 1).cuda()
+    net = pkg.ConvLSTM(3, [8], [9], 1).cuda()
     net.load_state_dict(params)
     with torch.no_grad():
         pred = net(X.cuda()).cpu()
     np.testing.assert_allclose(pred.numpy(), O.convlstm_forward(X, params).numpy(), rtol=1e-4, atol=1e-5)
-    with pytest.raises(pkg.NintError, match="layer 0.*k=7"):
+    with pytest.raises(pkg.NintError, match="layer 0.*k=9"):
         net(X.cuda())
