@@ -947,25 +947,36 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
     const bool in = cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
     float* dp = dpred + ((size_t)n * O * H + yy) * W + x;
     const float* yp = y + ((size_t)n * O * Hc + cy) * Wc + cx;
-    for (int o = 0; o < O; ++o) {
-      float p = b ? b[o] : 0.f;
+    // the targets of OU outputs are fetched before they are used: one dependent HBM round trip per OU outputs instead
+    // of one per output (the sums below still run in output order)
+    constexpr int OU = 4;
+    for (int o0 = 0; o0 < O; o0 += OU) {
+      float tq[OU];
 #pragma unroll
-      for (int c = 0; c < CHV; ++c)
-        if (c < Ch) p += w[o * Ch + c] * hv[c];
-      float gq = 0.f;
-      if (in) {
-        const float t = yp[(size_t)o * Hc * Wc];
-        const float d = p - t;
-        s2 += (double)d * d;
-        s1 += fabs((double)d);
-        sy += t;
-        syy += (double)t * t;
-        gq = (float)((2.0 * d + (d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0))) * inv_n);
+      for (int u = 0; u < OU; ++u) tq[u] = (in && o0 + u < O) ? yp[(size_t)(o0 + u) * Hc * Wc] : 0.f;
+#pragma unroll
+      for (int u = 0; u < OU; ++u) {
+        const int o = o0 + u;
+        if (o >= O) break;
+        float p = b ? b[o] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CHV; ++c)
+          if (c < Ch) p += w[o * Ch + c] * hv[c];
+        float gq = 0.f;
+        if (in) {
+          const float t = tq[u];
+          const float d = p - t;
+          s2 += (double)d * d;
+          s1 += fabs((double)d);
+          sy += t;
+          syy += (double)t * t;
+          gq = (float)((2.0 * d + (d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0))) * inv_n);
+        }
+        dp[(size_t)o * H * W] = gq;
+#pragma unroll
+        for (int c = 0; c < CHV; ++c)
+          if (c < Ch) acc[c] += w[o * Ch + c] * gq;
       }
-      dp[(size_t)o * H * W] = gq;
-#pragma unroll
-      for (int c = 0; c < CHV; ++c)
-        if (c < Ch) acc[c] += w[o * Ch + c] * gq;
     }
 #pragma unroll
     for (int c = 0; c < CHV; c += 4)
