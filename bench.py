@@ -242,14 +242,14 @@ def main():
         def k_pw():
             assert lib.nint_cell_bwd_pointwise(Ct.byref(ly), Ct.byref(g), eng.dt, B, vp(ws.gates[0].data_ptr() + gs),
                                                vp(ws.c[0].data_ptr() + cs), vp(ws.c[0].data_ptr() + 2 * cs), vp(ws.dh[0].data_ptr()),
-                                               vp(ws.dc[0].data_ptr()), vp(ws.dG[0].data_ptr() + dgs), vp(ws.dbp[0].data_ptr()), sp) == 0
+                                               vp(ws.dc[0].data_ptr()), vp(ws.dG[0].data_ptr() + dgs), sp) == 0
 
         dW0, db0 = trainer._dW[0], trainer._db[0]
 
         def k_wgrad():      # both sources (x and h) over all T time steps + the split-K fold + the bias-gradient fold
             assert lib.nint_conv_wgrad(Ct.byref(ly), Ct.byref(g), eng.dt, T * B, vp(ws.dG[0].data_ptr()), vp(ws.xs.data_ptr()),
                                        vp(ws.h[0].data_ptr()), vp(dW0.data_ptr()), vp(db0.data_ptr()), vp(eng.wg_partial.data_ptr()),
-                                       eng.wg_partial.numel() * 4, eng.n_cu, vp(ws.dbp[0].data_ptr()), T * 1024, sp) == 0
+                                       eng.wg_partial.numel() * 4, eng.n_cu, sp) == 0
 
         f_gate = 2.0 * B * Hp * Wp * k0 * k0 * (C + ch0) * 4 * ch0           # algorithmic, per launch
         f_dgrad = 2.0 * B * Hp * Wp * k0 * k0 * 4 * ch0 * ch0

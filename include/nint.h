@@ -35,8 +35,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 105
-#define NINT_DB_ROWS 1024   /* rows of bias-gradient partials one fused pointwise-backward launch writes */
+#define NINT_VERSION 106
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
 
@@ -93,7 +92,6 @@ typedef struct nint_seq {
   void* dx;                            /* ET compact [T*B][H][W][Cxp0] (need_dx only) */
   float* dW[NINT_MAX_LAYERS];          /* f32 OIHW (4Ch, Cx+Ch, k, k) gradient, overwritten */
   float* db[NINT_MAX_LAYERS];          /* f32 (4Ch) gradient, overwritten */
-  float* db_partial[NINT_MAX_LAYERS];  /* f32 [T][NINT_DB_ROWS][4*Ch16] bias-gradient partial rows (may be NULL) */
   float* wg_partial;                   /* f32 split-K slabs for wgrad: the SUM over the layers of nint_wgrad_workspace_bytes
                                         * (each rounded up to 256 bytes) -- the layers' slabs sit side by side */
   size_t wg_partial_bytes;
@@ -159,14 +157,23 @@ int nint_cell_fwd(const nint_layer* ly /*host*/, const nint_geom* g /*host*/, in
  * the stashed gates and c_prev / c_new; writes pre-activation gate grads into the dG halo slab. */
 int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                             const void* gates, const float* c_prev, const float* c_new,
-                            const void* dh, float* dc, void* dG, float* db_partial, void* stream);
-/* db_partial (may be NULL): f32 [NINT_DB_ROWS][4*Ch16], one row of bias-gradient partial sums per
- * workgroup of this launch (fused column sum of dG; needs 256 % (Ch16/4) == 0, else NINT_E_SHAPE). */
+                            const void* dh, float* dc, void* dG, void* stream);
 
 /* conv backward-data of model.py:220: d cat[x,h] = W^T (*) dG.  h columns are STORED to dh_prev,
  * x columns are ACCUMULATED (+=) into dx_accum (the layer below's dh, or dx); either may be NULL. */
 int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                     const void* dG, void* dx_accum, void* dh_prev, void* stream);
+
+/* One fused BPTT step of a cell: conv backward-data of time t+1 AND the pointwise backward of time t.
+ *   d cat[x,h]_{t+1} = W^T (*) dG_next;  x columns are STORED to dx (compact, may be NULL: not computed);
+ *   d/dh_t = (h columns) + dh_above  never goes to memory: it feeds the pointwise backward of time t (gates / c_prev /
+ *   c_new = the stash of time t; c_prev == NULL means c_{t-1} = 0), which overwrites dc in place (-> d/dc_{t-1}) and
+ *   writes the dG halo slab of time t.  dh_above: d/dh_t from the layer above (its x columns) or the head, compact
+ *   [N][H][W][Chp] ET; NULL = 0.  Same results as nint_conv_dgrad + nint_cell_bwd_pointwise up to the bf16 rounding of
+ *   the intermediate dh, which this entry skips. */
+int nint_cell_bwd_fused(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG_next, void* dx,
+                        const void* gates, const float* c_prev, const float* c_new, const void* dh_above,
+                        float* dc, void* dG, void* stream);
 
 /* conv backward-weight of model.py:220 over N = T*B images in ONE launch (all time steps):
  * dW[o][c][ky][kx] = sum_n,y,x dG[n,y,x,o] * cat[n,y+ky-p,x+kx-p,c] ; db[o] = sum dG.
@@ -174,10 +181,9 @@ int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
 size_t nint_wgrad_workspace_bytes(const nint_layer* ly, int dtype, int n_cu);
 int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                     const void* dG, const void* x_slab, const void* h_slab,
-                    float* dW, float* db, float* partial, size_t partial_bytes, int n_cu,
-                    const float* db_partial, int db_rows, void* stream);
-/* db_partial/db_rows: the rows written by the fused pointwise-backward launches of all time steps
- * (db = their column sum); NULL -> db is computed by a column-sum pass over dG instead. */
+                    float* dW, float* db, float* partial, size_t partial_bytes, int n_cu, void* stream);
+/* db rides along with the x source's weight gradient: the dG fragments are multiplied with an all-ones fragment on the
+ * matrix pipe (one extra column of the split-K slab), so there is no separate pass over dG. */
 
 /* ---- whole-sequence drivers (model.py:253-274 and its BPTT), all launches from C++ ---------- */
 int nint_seq_fwd(const nint_seq* s /*host*/, void* stream);

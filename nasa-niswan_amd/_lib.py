@@ -14,7 +14,6 @@ NINT_F32, NINT_BF16 = 0, 1
 NINT_MAX_LAYERS = 8
 NINT_LOSS_SCRATCH_FLOATS = 8194
 NINT_LOSS_STATS = 8
-NINT_DB_ROWS = 1024
 
 vp = C.c_void_p
 
@@ -36,7 +35,7 @@ class NintSeq(C.Structure):
                 ("xs", vp), ("h", vp * NINT_MAX_LAYERS), ("c", vp * NINT_MAX_LAYERS),
                 ("gates", vp * NINT_MAX_LAYERS), ("dG", vp * NINT_MAX_LAYERS), ("dh", vp * NINT_MAX_LAYERS),
                 ("dc", vp * NINT_MAX_LAYERS), ("dx", vp), ("dW", vp * NINT_MAX_LAYERS), ("db", vp * NINT_MAX_LAYERS),
-                ("db_partial", vp * NINT_MAX_LAYERS), ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t)]
+                ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t)]
 
 
 # every symbol include/nint.h declares: name -> (restype, argtypes)
@@ -60,10 +59,11 @@ SIGNATURES = {
     "nint_pack_btchw_xfold": (_I, [vp, vp, _I, _I, _I, _I, _I, _PG, _I, vp]),
     "nint_unfold_dx": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, _I, vp]),
     "nint_cell_fwd": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
-    "nint_cell_bwd_pointwise": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nint_cell_bwd_pointwise": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
     "nint_conv_dgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp]),
+    "nint_cell_bwd_fused": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nint_wgrad_workspace_bytes": (_SZ, [_PL, _I, _I]),
-    "nint_conv_wgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, _SZ, _I, vp, _I, vp]),
+    "nint_conv_wgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, _SZ, _I, vp]),
     "nint_seq_fwd": (_I, [_PS, vp]),
     "nint_seq_bwd": (_I, [_PS, vp]),
     "nint_head_fwd": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, _PG, _I, vp]),
@@ -97,7 +97,7 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nint_version() != 105:
+    if lib.nint_version() != 106:
         raise NintError("libnint_hip.so version mismatch")
     _lib = lib
     return lib

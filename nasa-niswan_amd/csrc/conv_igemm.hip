@@ -3,6 +3,8 @@
 // One kernel template serves both convolutions of the ConvLSTM cell:
 //   EPI_LSTM  : gates = W (*) cat[x,h] + b, sigmoid/tanh, c/h update      (reference model.py:219-229)
 //   EPI_DGRAD : d cat[x,h] = W^T (*) dG                                    (autograd of model.py:220)
+//   EPI_DGRAD_PW : the same, with the pointwise LSTM backward of the PREVIOUS time step (autograd of model.py:222-229)
+//                  run in the epilogue on the h columns while they are still accumulators
 //
 // GEMM view: M = pixels (16 consecutive x per MFMA row tile), N = output columns
 // (gate channels / cat channels), K = (64-byte channel chunk, tap).  The zero padding of
@@ -23,7 +25,7 @@
 //     n' = (cblock*4+gate)*16+col), so the LSTM epilogue needs no cross-lane traffic.
 #include "nint_common.h"
 
-enum { EPI_LSTM = 0, EPI_DGRAD = 1 };
+enum { EPI_LSTM = 0, EPI_DGRAD = 1, EPI_DGRAD_PW = 2 };
 
 // MT (template) = row tiles per wave = rows of the pixel tile: 8 for the wide launches (one weight
 // stream per 128 pixels), 4 for the short-K launches of the narrow layers, whose time is all halo
@@ -60,6 +62,24 @@ extern "C" int nint_debug_read_stamps(unsigned long long* host, int n_wgs) {
 #define NINT_STAMP_AT(slot)
 #endif
 
+// 4 consecutive elements kept PACKED until they are used (bf16: 2 registers instead of 4)
+template <int DT> struct Pk4;
+template <> struct Pk4<NINT_F32> {
+  typedef f32x4_t T;
+  static __device__ __forceinline__ T ld(const void* p, size_t i) { return *(const f32x4_t*)((const float*)p + i); }
+  static __device__ __forceinline__ f32x4_t up(T v) { return v; }
+  static __device__ __forceinline__ T zero() { return (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+};
+template <> struct Pk4<NINT_BF16> {
+  typedef u32x2_t T;
+  static __device__ __forceinline__ T ld(const void* p, size_t i) { return *(const u32x2_t*)((const uint16_t*)p + i); }
+  static __device__ __forceinline__ f32x4_t up(T w) {
+    return (f32x4_t){__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                     __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ T zero() { return (u32x2_t){0u, 0u}; }
+};
+
 // Rounds of the K-slice exchange.  Four K-slices of a 4-row tile park 3/4 of the accumulators: in ONE round that
 // buffer (12 KiB per wave, 48 KiB) is the workgroup's whole LDS footprint for the narrow layers and caps them at 3
 // workgroups per CU; in two rounds of half the column tiles it is 24 KiB (under the halo image) and a fourth fits.
@@ -70,7 +90,7 @@ constexpr int xchg_rounds(int EPI, int WK, int NTW, int MT) {
 }
 
 template <int DT, int EPI, int WN, int WK, int NTW, int MT>
-__global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) == 2 && DT == NINT_BF16 ? 4 : 3)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) == 2 && DT == NINT_BF16 && EPI != EPI_DGRAD_PW ? 4 : 3)) void conv_igemm_kernel(ConvArgs a) {
   static_assert(WN * WK == 4, "four waves per workgroup");
   constexpr int BD = MT >= 8 ? BD_WIDE : BD_NARROW;
   static_assert(EPI != EPI_LSTM || NTW % 4 == 0, "LSTM epilogue needs the 4 gate tiles in one wave");
@@ -81,6 +101,13 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef NINT_EXPERIMENT
+  if (EPI == EPI_DGRAD_PW && (a.dbg >> 8) && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1)) {
+    // stagger experiment: the second workgroup of each CU starts (dbg >> 8) microseconds late
+    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + 100ull * (a.dbg >> 8);
+    while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wk = wave / WN;
@@ -150,7 +177,16 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   for (int i = 0; i < MT; ++i) rowoff[i] = (rdy((i + wk * Q) % MT) * HWt + rdx((i + wk * Q) % MT)) * 16;
   const char* Bwave = a.Bp + (size_t)nt0 * 1024;   // wave-uniform (scalar) base; the lane part is a 32-bit offset
   const unsigned blane = lane * 16;
+#ifdef NINT_EXPERIMENT
+  // ablations (experiment build only, results are wrong): 0x10 weight stream re-reads one K-step (L1 hits),
+  // 0x20 no epilogue stores, 0x40 no halo fill
+  const size_t bstep = (a.dbg & 0x10) ? 0 : (size_t)a.NTt * 1024;
+  const bool abl_nostore = a.dbg & 0x20;
+  const bool abl_nofill = (a.dbg & 0x40) || ((a.dbg & 0x80) && (int)blockIdx.x >= 256 * (MT >= 8 ? 2 : 4));   // 0x80: second-round workgroups only
+#else
   const size_t bstep = (size_t)a.NTt * 1024;   // bytes between consecutive K-steps in Bp
+  constexpr bool abl_nostore = false, abl_nofill = false;
+#endif
 
   // c_{t-1} of the rows this wave finishes in the epilogue (rows (i + wk*Q) % MT, see the K-slice exchange below).
   // 4-row tiles (the narrow layers, whose time is all memory latency) fetch it HERE, ahead of the halo fill: the loads
@@ -205,7 +241,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     const int c_cnt = min(a.cpf, nchunks - c_begin);
     if (c_begin > 0) __syncthreads();          // every wave is done reading the previous image
     // ---- stage the halo tile for chunks [c_begin, c_begin+c_cnt): global -> LDS ----
-    const int a_units = c_cnt * 4 * NHPp;
+    const int a_units = abl_nofill ? 0 : c_cnt * 4 * NHPp;
     // LDS-DMA fill: one global_load_lds_dwordx4 per wave moves 64 consecutive 16-byte units of the image
     // (wave-uniform LDS base + lane*16; the SOURCE address is per lane), no VGPR round trip, so the whole
     // image is in flight at once instead of FB loads per thread.  Units of the pad pixels re-read pixel 0
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
       for (int i = 0; i < Q; ++i) {
         const int rt = (i + wk * Q) % MT;        // row tile of the workgroup
         const int y = y0 + rdy(rt), xo = rdx(rt);
-        const bool ok = y < a.H && x + xo < a.W; // (the lane exchange below needs every lane: no divergent block)
+        const bool ok = y < a.H && x + xo < a.W && !abl_nostore; // (the lane exchange below needs every lane: no divergent block)
         const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;   // (a merged tile's second column: 16 pixels on)
         const f32x4_t cp = cpv[i][cb];
         f32x4_t gi, gf, gg, go, cn, hn;
@@ -481,6 +517,89 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
         }
       }
     }
+  } else if constexpr (EPI == EPI_DGRAD_PW) {
+    // Fused BPTT step.  This launch is dgrad(t+1) of the layer; its h columns are d/dh_t from the layer's own
+    // recurrence -- the last contribution to dh_t (the layer above already left its x columns of time t in pw_old) --
+    // so the pointwise backward of time t runs HERE, on the accumulators: dh_t never goes to memory, and the
+    // HBM-bound pass (34 bytes per channel-pixel) hides behind the matrix work of the CU's other workgroup.
+    //   dct = dc + dh*o*(1 - tanh(c_t)^2);  dG = (dct*g*i(1-i), dct*c_{t-1}*f(1-f), dct*i*(1-g^2), dh*tanh(c_t)*o(1-o))
+    //   dc <- dct*f                                                     (autograd of model.py:222-229)
+    // x columns are STORED: in the fused schedule they are the only writer of their destination.
+    // All loads of a batch of rows are issued before its first store (vmcnt retires in order and counts stores).
+    typedef Pk4<DT> PK;
+    const int Gc = 4 * a.Ch16;
+    constexpr int RB0 = NTW >= 4 ? 1 : 4 / NTW;                  // rows per batch: about 4 column tiles (88 registers) in flight
+    constexpr int RB = RB0 >= Q ? Q : (Q % RB0 == 0 ? RB0 : 1);
+#pragma unroll
+    for (int ib = 0; ib < Q; ib += RB) {
+      typename PK::T gq[RB][NTW][4], oldv[RB][NTW];
+      f32x4_t cpq[RB][NTW], cnq[RB][NTW], dcq[RB][NTW];
+#pragma unroll
+      for (int ii = 0; ii < RB; ++ii) {
+        const int rt = (ib + ii + wk * Q) % MT;
+        const int y = y0 + rdy(rt), xo = rdx(rt);
+        const bool okp = y < a.H && x + xo < a.W;
+        const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int hch = (nt0 + j) * 16 - a.C0p;                 // first hidden channel of this column tile (tile-uniform)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gq[ii][j][q] = PK::zero();
+          oldv[ii][j] = PK::zero();
+          cpq[ii][j] = cnq[ii][j] = dcq[ii][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (hch >= 0 && hch < a.Ch16 && okp) {
+            const size_t pix = rowpix + x;
+            const size_t gb = pix * Gc + (size_t)(hch >> 4) * 64 + c4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gq[ii][j][q] = PK::ld(a.pw_gates, gb + 16 * q);
+            const size_t ci = pix * a.Chp + hch + c4;
+            if (a.pw_c_prev) cpq[ii][j] = *(const f32x4_t*)(a.pw_c_prev + ci);
+            cnq[ii][j] = *(const f32x4_t*)(a.pw_c_new + ci);
+            dcq[ii][j] = *(const f32x4_t*)(a.pw_dc + ci);
+            if (a.pw_old) oldv[ii][j] = PK::ld(a.pw_old, ci);
+          }
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < RB; ++ii) {
+        const int i = ib + ii;
+        const int rt = (i + wk * Q) % MT;
+        const int y = y0 + rdy(rt), xo = rdx(rt);
+        const bool okp = y < a.H && x + xo < a.W;
+        const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int n = (nt0 + j) * 16 + c4;
+          const int hch = (nt0 + j) * 16 - a.C0p;
+          if (hch < 0) {
+            if (a.out0 && okp) store_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + n), acc[i][j]);
+          } else if (hch < a.Ch16 && okp) {
+            const f32x4_t gi = PK::up(gq[ii][j][0]), gf = PK::up(gq[ii][j][1]), gg = PK::up(gq[ii][j][2]), go = PK::up(gq[ii][j][3]);
+            const f32x4_t dhv = acc[i][j] + PK::up(oldv[ii][j]);
+            const f32x4_t cp = cpq[ii][j], cn = cnq[ii][j], dcv = dcq[ii][j];
+            f32x4_t o_i, o_f, o_g, o_o, dcp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float tc = tanhf_(cn[e]);
+              const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
+              const float d_o = dhv[e] * tc;
+              o_i[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+              o_f[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+              o_g[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+              o_o[e] = d_o * go[e] * (1.f - go[e]);
+              dcp[e] = dct * gf[e];
+            }
+            char* grow = a.pw_dG + ((((size_t)img * a.Hh) + (y + a.P)) * a.Wh + (xo + a.P)) * Gc * Elem<DT>::ES;
+            const unsigned ob = (unsigned)(x * Gc + (hch >> 4) * 64 + c4);
+            store_vec4<DT>(grow, ob, o_i);
+            store_vec4<DT>(grow, ob + 16, o_f);
+            store_vec4<DT>(grow, ob + 32, o_g);
+            store_vec4<DT>(grow, ob + 48, o_o);
+            *(f32x4_t*)(a.pw_dc + (rowpix + x) * a.Chp + hch + c4) = dcp;
+          }
+        }
+      }
+    }
   } else {
     // x columns accumulate into (or overwrite) the layer below's dh / dx, h columns are stored to dh_prev.
     // Addresses = wave-uniform row base + row-invariant lane offset; the read-modify-write loads of ALL rows are
@@ -491,7 +610,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     for (int i = 0; i < Q; ++i) {
       const int rt = (i + wk * Q) % MT;
       const int y = y0 + rdy(rt), xo = rdx(rt);
-      if (y < a.H && x + xo < a.W) {
+      if (y < a.H && x + xo < a.W && !abl_nostore) {
         const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -571,7 +690,7 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   // (measured with the leftover strip merged, B = 8, 100x154: dgrad layer 0 -- 200 steps, 4 column tiles -- 94.7 us with
   // 8-row tiles against 104.0; dgrad layer 1 -- 36 steps -- 40.2 against 41.5; the 18-27-step launches prefer 4 rows)
   const bool mt4 = a.tile_rows ? a.tile_rows == 4
-                               : (EPI == EPI_DGRAD ? ksteps <= 32 : (ksteps <= 48 || ntiles <= 4));
+                               : (EPI != EPI_LSTM ? ksteps <= 32 : (ksteps <= 48 || ntiles <= 4));
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;
@@ -580,9 +699,9 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
     return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st);
   } else {
 #ifdef NINT_EXPERIMENT
-    if (a.dbg == 1 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 8>(a, N, ntiles / 4, st);
-    if (a.dbg == 2 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 4>(a, N, ntiles / 4, st);
-    if (a.dbg == 3 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 1, 8>(a, N, ntiles / 4, st);
+    if ((a.dbg & 15) == 1 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 8>(a, N, ntiles / 4, st);
+    if ((a.dbg & 15) == 2 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 4>(a, N, ntiles / 4, st);
+    if ((a.dbg & 15) == 3 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 1, 8>(a, N, ntiles / 4, st);
 #endif
     // (WN, NTW) with WN*NTW dividing the tile count, widest first; leftover waves split K
     if (ntiles % 16 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, ntiles / 16, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, ntiles / 16, st);
@@ -641,14 +760,15 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
 
 extern "C" int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
                                const void* dG, void* dx_accum, void* dh_prev, void* stream) {
-  return nint_internal_conv_dgrad(ly, g, dtype, N, dG, dx_accum, dh_prev, false, stream);
+  return nint_internal_conv_dgrad(ly, g, dtype, N, dG, dx_accum, dh_prev, false, nullptr, stream);
 }
 
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
-                             void* dh_prev, bool overwrite_dx, void* stream) {
+                             void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream) {
   if (!ly || !g || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
-  if (!dx_accum && !dh_prev) return NINT_OK;
+  if (pw && (!pw->gates || !pw->c_new || !pw->dc || !pw->dG_out || dh_prev)) return NINT_E_ARG;
+  if (!dx_accum && !dh_prev && !pw) return NINT_OK;
   if (!aligned16(dG) || !aligned16(ly->Wd)) return NINT_E_ALIGN;
 #ifndef NINT_EXPERIMENT
   if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
@@ -670,16 +790,30 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.out0 = (char*)dx_accum; a.out1 = (char*)dh_prev;
   a.out0_overwrite = overwrite_dx ? 1 : 0;
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
+  a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
   a.tile_rows = ly->tile_rows;
 #ifdef NINT_EXPERIMENT
   a.dbg = ly->tile_rows >> 8;                 // experiment build: selector in the upper bits
   a.tile_rows = ly->tile_rows & 0xff;
 #endif
-  // only the n-tiles whose destination exists are computed
-  const int nt_x = ly->Cxp / 16, nt_h = ly->Chp / 16;
+  // only the n-tiles whose destination exists are computed (fused: the Ch16 real hidden columns, not their padding)
+  const int nt_x = ly->Cxp / 16, nt_h = pw ? ly->Ch16 / 16 : ly->Chp / 16;
   a.nt_begin = dx_accum ? 0 : nt_x;
-  const int ntiles = (dx_accum ? nt_x : 0) + (dh_prev ? nt_h : 0);
+  const int ntiles = (dx_accum ? nt_x : 0) + ((dh_prev || pw) ? nt_h : 0);
   hipStream_t st = (hipStream_t)stream;
+  if (pw) {
+    a.pw_gates = (const char*)pw->gates; a.pw_c_prev = pw->c_prev; a.pw_c_new = pw->c_new; a.pw_dc = pw->dc;
+    a.pw_old = (const char*)pw->old; a.pw_dG = (char*)pw->dG_out;
+    return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD_PW>(a, N, ntiles, st)
+                              : launch_conv<NINT_F32, EPI_DGRAD_PW>(a, N, ntiles, st);
+  }
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD>(a, N, ntiles, st)
                             : launch_conv<NINT_F32, EPI_DGRAD>(a, N, ntiles, st);
+}
+
+extern "C" int nint_cell_bwd_fused(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG_next, void* dx,
+                                   const void* gates, const float* c_prev, const float* c_new, const void* dh_above,
+                                   float* dc, void* dG, void* stream) {
+  const DgradPw pw = {gates, c_prev, c_new, dc, dh_above, dG};
+  return nint_internal_conv_dgrad(ly, g, dtype, N, dG_next, dx, nullptr, true, &pw, stream);
 }

@@ -146,20 +146,29 @@ struct ConvArgs {
   char* out1;            // =  columns [C0p, C0p+C1p)  (ET compact)
   int C0p, C1p;
   int out0_overwrite;    // 1: columns [0, C0p) are stored, not accumulated (the destination is known to be zero)
+  // DGRAD_PW epilogue: the pointwise LSTM backward of the previous time step on the h columns (Chp / Ch16 as above)
+  const char* pw_gates;  // gate stash of that step [N][H][W][4*Ch16] ET
+  const float* pw_c_prev;// c_{t-1} compact f32 or nullptr (= 0)
+  const float* pw_c_new; // c_t
+  float* pw_dc;          // d/dc, read and overwritten in place
+  const char* pw_old;    // the x columns the layer above left for this step (ET compact [N][H][W][Chp]) or nullptr
+  char* pw_dG;           // dG halo slab of that step
 };
 
 // internal entry points shared between translation units (not part of the C ABI)
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
-                                     float* db_partial, bool dc_zero, void* stream);
+                                     bool dc_zero, void* stream);
 struct WgJob {           // one layer's weight / bias gradient
   const nint_layer* ly; int N;
   const void* dG; const void* x_slab; const void* h_slab;
   float* dW; float* db;
-  const float* db_partial; int db_rows;      // fused bias-gradient partial rows (or NULL: column-sum pass over dG)
   int h_skip;                                // leading images whose h source is identically zero
 };
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
                                    size_t partial_bytes, int n_cu, void* stream);
+struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
+  const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
+};
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
-                             void* dh_prev, bool overwrite_dx, void* stream);
+                             void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream);

@@ -463,19 +463,16 @@ extern "C" int nint_pack_weights_layers(const float* const* W, const float* cons
 // interior only) and dc_prev in place.  One thread per (pixel, channel), channel fastest.
 // 4 consecutive elements as f32 (16-byte f32 / 8-byte bf16 vector load); i must be a multiple of 4
 // One thread per (pixel, 4 consecutive hidden channels): every access is a 16-byte (f32) or 8-byte
-// (bf16) vector.  With FUSE_DB each thread keeps the SAME channel quad over its grid-stride loop
-// (256 % (Ch16/4) == 0), accumulates the 16 bias-gradient partial sums in registers and the block
-// writes one row of db_partial[gridDim.x][4*Ch16] -- fixed order, no atomics; the rows are folded
-// by nint_conv_wgrad.  This replaces a separate full pass over dG.
-template <int DT, bool FUSE_DB>
+// (bf16) vector.  (The bias gradient, the column sums of dG, is produced by the weight-gradient kernel, which has the
+// dG fragments in registers anyway: wgrad.hip.)
+template <int DT>
 __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
                                           const float* __restrict__ c_new, const void* __restrict__ dh,
-                                          float* __restrict__ dc, void* __restrict__ dG, float* __restrict__ db_partial,
+                                          float* __restrict__ dc, void* __restrict__ dG,
                                           int N, int H, int W, int P, int Hh, int Wh, int Ch16, int Chp, int dc_zero) {
   const int nq = Ch16 >> 2;
   const size_t total = (size_t)N * H * W * nq;
   const int Gc = 4 * Ch16;
-  f32x4_t s_i = {0.f, 0.f, 0.f, 0.f}, s_f = s_i, s_g = s_i, s_o = s_i;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int q = i % nq;
     const size_t pix = i / nq;
@@ -515,42 +512,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __r
     store_vec4<DT>(dG, ob + 32, o_g);
     store_vec4<DT>(dG, ob + 48, o_o);
     *(f32x4_t*)(dc + ci) = dcp;
-    if constexpr (FUSE_DB) { s_i += o_i; s_f += o_f; s_g += o_g; s_o += o_o; }
-  }
-  if constexpr (FUSE_DB) {
-    __shared__ float red[16][256 + 4];
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[0 + e][t] = s_i[e]; red[4 + e][t] = s_f[e]; red[8 + e][t] = s_g[e]; red[12 + e][t] = s_o[e];
-    }
-    __syncthreads();
-    const int groups = 256 / nq;
-    for (int o = t; o < Gc; o += 256) {
-      const int v = o / nq, q = o % nq;          // v = gate*4 + e
-      float acc = 0.f;
-      for (int g = 0; g < groups; ++g) acc += red[v][g * nq + q];
-      const int gate = v >> 2, ch = 4 * q + (v & 3);
-      db_partial[(size_t)blockIdx.x * Gc + (ch >> 4) * 64 + gate * 16 + (ch & 15)] = acc;
-    }
   }
 }
 
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
-                                     float* db_partial, bool dc_zero, void* stream) {
+                                     bool dc_zero, void* stream) {
   if (!ly || !g || !gates || !c_new || !dh || !dc || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
-  const int nq = ly->Ch16 / 4;
-  if (db_partial && 256 % nq != 0) return NINT_E_SHAPE;     // caller falls back to the column-sum pass
-  const size_t total = (size_t)N * g->H * g->W * nq;
+  const size_t total = (size_t)N * g->H * g->W * (ly->Ch16 / 4);
   hipStream_t st = (hipStream_t)stream;
-  // a fused launch always has exactly NINT_DB_ROWS blocks (idle blocks write zero rows)
-  const dim3 grid = db_partial ? dim3(NINT_DB_ROWS) : grid1d(total);
-#define NINT_PW(DT_, F_) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<DT_, F_>), grid, dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, \
-                                            db_partial, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp, dc_zero ? 1 : 0)
-  if (dtype == NINT_BF16) { if (db_partial) NINT_PW(NINT_BF16, true); else NINT_PW(NINT_BF16, false); }
-  else { if (db_partial) NINT_PW(NINT_F32, true); else NINT_PW(NINT_F32, false); }
+  const dim3 grid = grid1d(total);
+#define NINT_PW(DT_) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<DT_>), grid, dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, \
+                                        N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp, dc_zero ? 1 : 0)
+  if (dtype == NINT_BF16) NINT_PW(NINT_BF16); else NINT_PW(NINT_F32);
 #undef NINT_PW
   NINT_LAUNCH_CHECK();
   return NINT_OK;
@@ -558,8 +533,8 @@ int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, i
 
 extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                        const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
-                                       float* db_partial, void* stream) {
-  return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, db_partial, false, stream);
+                                       void* stream) {
+  return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, false, stream);
 }
 
 // ------------------------------------------------------------------------------ 1x1 head

@@ -153,14 +153,11 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       const size_t Gc = 4 * (size_t)ly->Ch16;
       const char* gates = (const char*)s->gates[l] + (size_t)t * B * comp_px * Gc * es;
       char* dG = (char*)s->dG[l] + (size_t)t * B * halo_px * Gc * es;
-      // bias-gradient partial rows of this (t, l): fused into the pointwise pass when the shape allows
-      float* dbp = (s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0)
-                       ? s->db_partial[l] + (size_t)t * NINT_DB_ROWS * Gc : nullptr;
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
       const bool first = t == s->T - 1;
       rc = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
-                                            s->dh[l], s->dc[l], dG, dbp, first && ((s->zero_dstate >> (2 * l)) & 1), stream);
+                                            s->dh[l], s->dc[l], dG, first && ((s->zero_dstate >> (2 * l)) & 1), stream);
       if (rc != NINT_OK) return rc;
       void* dx_accum = (l > 0) ? s->dh[l - 1]
                                : (s->need_dx ? (void*)((char*)s->dx + (size_t)t * B * comp_px * ly->Cxp * es) : nullptr);
@@ -169,7 +166,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // the x columns overwrite instead of accumulate where the destination is known to be zero: dx (every time
       // step has its own slab, written once) and, at the first step, a dh[l-1] flagged zero
       const bool ow = l == 0 ? true : (first && ((s->zero_dstate >> (2 * (l - 1) + 1)) & 1));
-      rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, ow, stream);
+      rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, ow, nullptr, stream);
       if (rc != NINT_OK) return rc;
     }
   }
@@ -177,12 +174,11 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   WgJob jobs[NINT_MAX_LAYERS];
   for (int l = 0; l < L; ++l) {
     const nint_layer* ly = &s->layer[l];
-    const bool fused_db = s->db_partial[l] && 256 % (ly->Ch16 / 4) == 0;
     const char* x_all = (l == 0) ? (const char*)s->xs
                                  : (const char*)s->h[l - 1] + (size_t)B * halo_px * ly->Cxp * es;  // h^{l-1}_t = slab t+1
     // h_{-1} = 0 for a sequence from the zero state: the h part of the reduction skips time step 0
     jobs[l] = WgJob{ly, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
-                    fused_db ? s->db_partial[l] : nullptr, s->T * NINT_DB_ROWS, s->has_init_state ? 0 : B};
+                    s->has_init_state ? 0 : B};
   }
   rc = nint_internal_conv_wgrad_multi(jobs, L, g, s->dtype, s->wg_partial, s->wg_partial_bytes, s->n_cu, stream);
   if (rc != NINT_OK) return rc;

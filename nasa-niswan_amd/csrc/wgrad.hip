@@ -13,6 +13,10 @@
 //         all a reduction needs.
 //   f32 : plain ds_read_b32 (lane = channel) feeding v_mfma_f32_16x16x4_f32.
 // Taps are free: the cat image is a halo tile and a tap is a constant LDS address offset.
+// The bias gradient db[o] = sum_pixels dG[.,o] rides along: the dG fragments are in registers anyway, so ONE wave of the
+// workgroups that own channel block 0 of the x source multiplies them with an all-ones fragment (4 extra MFMAs per
+// pixel row on the wave with the fewest columns); the result is one more column of the partial slab, folded by the
+// same reduction launch.  No separate pass over dG, no per-step partial rows in the BPTT kernels.
 // Each workgroup keeps its 64 x (16*NTC*taps) output block in accumulators for its whole pixel
 // range and writes ONE partial slab; a second kernel folds the slabs in fixed order
 // (bitwise reproducible, no float atomics) into the OIHW gradient.
@@ -28,6 +32,7 @@ struct WgradArgs {
   int k, p, taps;
   int P, Wh;
   int tiles_x, tiles_y, ntiles, tiles_per_split;
+  int want_db;           // 1: the slab's last column (JG-1) carries the bias gradient (column sums of dG), see below
 };
 
 template <int DT> struct WgTile;
@@ -83,6 +88,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   for (int i = 0; i < NTN; ++i)
 #pragma unroll
     for (int j = 0; j < JW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // bias gradient: channel block 0 / LAST column group of the source that carries it, on the last wave -- which has
+  // fewer than JW real columns there (host-checked), so its accumulator column JW-1 is free: no extra registers
+  const bool do_db = __builtin_amdgcn_readfirstlane((a.want_db && cb == 0 && tg == a.TG - 1 && wave == 3 && NS == 1) ? 1 : 0);
 
   // DMA pieces of a tile are dealt to the waves in CONTIGUOUS ranges sized to even out each wave's work per tile:
   // a wave with fewer real columns (25 taps over 4 waves = 7, 7, 7, 4) has idle issue slots that the staging of the
@@ -215,8 +224,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   // inside it the column count is a compile-time constant, so a tile is ONE basic block -- the compiler is free to
   // hoist the transposed reads of pixel row pr+1 above the MFMAs of row pr -- and no MFMA is predicated.  Every variant
   // issues the same DMA pieces and the same barriers.
-  auto run_tiles = [&](auto nvc) __attribute__((always_inline)) {
+  auto run_tiles = [&](auto nvc, auto dbc) __attribute__((always_inline)) {
     constexpr int NV = decltype(nvc)::value;
+    constexpr bool DB = decltype(dbc)::value;
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int cur = (tile - t_begin) & 1;
       const bool more = tile + 1 < t_end;
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       const char* Bb[JW];
 #pragma unroll
       for (int jj = 0; jj < JW; ++jj) Bb[jj] = smem + cur * buf_bytes + vB[jj];
-      if constexpr (NV > 0 && DT == NINT_BF16) {
+      if constexpr ((NV > 0 || DB) && DT == NINT_BF16) {
 #pragma unroll
         for (int pr = 0; pr < PR; ++pr) {
           // pixel -> K-slot: read rd covers pixels rd*16 + 4*g + q of the 32-pixel row segment
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
             return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
           };
-          u32x4_t af[NTN], bf[NV];
+          u32x4_t af[NTN], bf[NV > 0 ? NV : 1];
 #pragma unroll
           for (int i = 0; i < NTN; ++i) af[i] = read_tr(Ab + pr * 32 * RA + i * 32, 16 * RA);
 #pragma unroll
@@ -244,8 +254,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
           for (int jj = 0; jj < NV; ++jj)
 #pragma unroll
             for (int i = 0; i < NTN; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf[jj], acc[i][jj]);
+          if constexpr (DB) {                  // D[gate column][.] += sum over the 32 pixels of this row segment
+            const u32x4_t ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+            for (int i = 0; i < NTN; ++i) acc[i][JW - 1] = mma_step<NINT_BF16>(af[i], ones, acc[i][JW - 1]);
+          }
         }
-      } else if constexpr (NV > 0) {
+      } else if constexpr (NV > 0 || DB) {
 #pragma unroll
         for (int pr = 0; pr < PR; ++pr) {
 #pragma unroll
@@ -264,6 +279,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
                 for (int i = 0; i < NTN; ++i)
                   acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][jj], 0, 0, 0);
               }
+              if constexpr (DB) {
+#pragma unroll
+                for (int i = 0; i < NTN; ++i) acc[i][JW - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], 1.0f, acc[i][JW - 1], 0, 0, 0);
+              }
             }
           }
         }
@@ -272,9 +291,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       __syncthreads();                           // ... for every wave, and this one is fully read
     }
   };
-  if (nvalid == JW) run_tiles(std::integral_constant<int, JW>{});
-  else if (nvalid == NVL) run_tiles(std::integral_constant<int, NVL>{});
-  else run_tiles(std::integral_constant<int, 0>{});      // a wave without real columns only stages and synchronises
+  if (do_db) {                                            // (wave 3 of the last group: NVL < JW columns, or none)
+    if (NVL < JW && nvalid == NVL) run_tiles(std::integral_constant<int, NVL < JW ? NVL : 0>{}, std::true_type{});
+    else run_tiles(std::integral_constant<int, 0>{}, std::true_type{});
+  } else {
+    if (nvalid == JW) run_tiles(std::integral_constant<int, JW>{}, std::false_type{});
+    else if (nvalid == NVL) run_tiles(std::integral_constant<int, NVL>{}, std::false_type{});
+    else run_tiles(std::integral_constant<int, 0>{}, std::false_type{});      // a wave without real columns only stages and synchronises
+  }
 
   // ---- flush: partial[split][blockIdx.y][j local][n'loc 64][c 16]
   float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * a.JG * 1024;
@@ -289,6 +313,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
           out[(size_t)j * 1024 + ((i0 + i) * 16 + 4 * g + r) * 16 + i16] = acc[i][jj][r];
     }
   }
+  if (do_db) {                                            // slab column JG-1: all 16 "channel" columns hold the same sum
+#pragma unroll
+    for (int i = 0; i < NTN; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(size_t)(a.JG - 1) * 1024 + ((i0 + i) * 16 + 4 * g + r) * 16 + i16] = acc[i][JW - 1][r];
+  }
 }
 
 // Fold the split-K slabs of ONE source (x or h part) into dW (OIHW f32).  A workgroup owns 64 consecutive
@@ -298,7 +329,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 struct ReduceEntry {
   const float* part; float* dW;
   int Cx, Ch, Ch16, k, NB, CB, NTC, J, splits, is_h, xfold;
-  int TG, JG;                               // column groups per block column, columns per block slab
+  int TG, JG;                               // column groups per block column, columns per block slab (incl. the db column)
+  float* db;                                // non-NULL: slab column JG-1 of (channel block 0, last group) is the bias gradient
   int waves;                                // waves that share the splits of one 64-element line (the others exit)
   unsigned blk_begin;                       // first workgroup of this (layer, source) in the merged launch
 };
@@ -332,13 +364,18 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   const int tgi = r % TG; r /= TG;
   const int cb = r % CB;
   const int nb = r / CB;
-  const int j = tgi * JG + jl;
+  const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
+  const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
+  const int JR = JG - (E.db ? 1 : 0);                 // real columns per group
+  if (jl >= JR) {                                     // the bias-gradient column
+    if (cb == 0 && tgi == TG - 1 && c16 == 0 && ch < Ch) E.db[gate * Ch + ch] = s;
+    return;
+  }
+  const int j = tgi * JR + jl;
   if (j >= J) return;                                 // unused slots of the last column group
   int tap = j / NTC;
   const int ct = j - tap * NTC;
   int cc = (cb * NTC + ct) * 16 + c16;                // channel inside this source
-  const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
-  const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
   int Csrc = is_h ? Ch : Cx;
   if (!is_h && E.xfold) {                             // folded x source: column (ky, kx*Cx + c) -> W[.][c][ky][kx]
     if (cc >= k * Cx) return;
@@ -350,80 +387,12 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
 }
 
-struct BiasEntry { const float* m; float* partial; float* db; int rows, ld, Ch; };     // one layer's bias-gradient fold
-struct BiasTable { BiasEntry e[NINT_MAX_LAYERS]; int n; };
-
-// column sums of row-major f32 matrices [rows][ld] (the bias-gradient partial rows of layer blockIdx.z) over columns
-// [64*blockIdx.x, +64): block = 64 columns x blockDim/64 row lanes, grid.y row groups; partial[blockIdx.y][ld].  Fixed order.
-__global__ void rowsum_partial_kernel(BiasTable t) {
-  __shared__ float red[1024];
-  const BiasEntry& E = t.e[blockIdx.z];
-  if (!E.m) return;                                                       // this layer's partial rows come from colsum_partial_kernel
-  const int ld = E.ld, rows = E.rows;
-  if ((int)blockIdx.x * 64 >= ld) return;
-  const float* __restrict__ m = E.m;
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, G = blockDim.x >> 6;
-  float acc = 0.f;
-  if (col < ld) {
-#pragma unroll 4
-    for (int r = blockIdx.y * G + sub; r < rows; r += gridDim.y * G) acc += m[(size_t)r * ld + col];
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (sub != 0 || col >= ld) return;
-  for (int q = 1; q < G; ++q) acc += red[q * 64 + (threadIdx.x & 63)];
-  E.partial[(size_t)blockIdx.y * ld + col] = acc;
-}
-
-// db[o] = sum over all pixels of dG[.,o]: grid = (row splits, column groups of 64); fixed order.
-template <int DT>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ dG, float* __restrict__ partial,
-                                                             int N, int H, int W, int P, int Hh, int Wh, int Gc) {
-  const int colgrp = blockIdx.y, col = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  const size_t npix = (size_t)N * H * W;
-  float acc = 0.f;
-  for (size_t pidx = (size_t)blockIdx.x * 4 + sub; pidx < npix; pidx += (size_t)gridDim.x * 4) {
-    const int x = pidx % W;
-    size_t r = pidx / W;
-    const int y = r % H;
-    const int n = r / H;
-    acc += load_elem<DT>(dG, ((((size_t)n * Hh) + (y + P)) * Wh + (x + P)) * Gc + colgrp * 64 + col);
-  }
-  __shared__ float red[256];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (sub == 0) partial[((size_t)blockIdx.x * gridDim.y + colgrp) * 64 + col] = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
-}
-
-// db[o] = sum of the partial rows of layer blockIdx.y; block = 64 outputs x blockDim/64 row lanes
-__global__ void colsum_final_kernel(BiasTable t, int nrows) {
-  __shared__ float red[1024];
-  const BiasEntry& E = t.e[blockIdx.y];
-  const int Ch = E.Ch, Gc = E.ld;
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, G = blockDim.x >> 6;
-  if ((int)blockIdx.x * 64 >= 4 * Ch) return;
-  const bool ok = o < 4 * Ch;
-  float s = 0.f;
-  if (ok) {
-    const int gate = o / Ch, ch = o % Ch;
-    const int np = (ch >> 4) * 64 + gate * 16 + (ch & 15);
-#pragma unroll 4
-    for (int r = sub; r < nrows; r += G) s += E.partial[(size_t)r * Gc + np];
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (sub != 0 || !ok) return;
-  for (int q = 1; q < G; ++q) s += red[q * 64 + (threadIdx.x & 63)];
-  E.db[o] = s;
-}
-
 // ------------------------------------------------------------------------------ host side
 struct WgPart { int NTC, J, JW, KX, CB, TG, JG, splits; };   // one source (x or h) of the reduction
 struct WgPlan {
   WgPart part[2];
   int NB, tiles_x, tiles_y, ntiles;
-  size_t off_h, off_db, total_floats;
-  int db_rows;
+  size_t off_h, total_floats;
 };
 
 static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_geom* g, WgPlan* pl) {
@@ -447,8 +416,9 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
     // more than 4*JW columns (the 49 taps of a 7x7 kernel): column groups on extra workgroups; only whole waves of
     // columns there (the tile loop exists for JW, J % JW and 0 columns per wave)
     w.TG = nint_cdiv(w.J, 4 * w.JW);
-    w.JG = w.TG == 1 ? w.J : 4 * w.JW;
+    w.JG = (w.TG == 1 ? w.J : 4 * w.JW) + (q == 0 ? 1 : 0);     // the x part's slabs carry the bias-gradient column
     if (w.TG > 1 && w.J % w.JW) return NINT_E_SHAPE;
+    if (q == 0 && w.J - (w.TG - 1) * 4 * w.JW > 3 * w.JW + (w.JW - 1)) return NINT_E_SHAPE;   // the db column needs wave 3's last accumulator column free
     const int CW = 16 * w.NTC;
     if (Cp % CW) return NINT_E_SHAPE;
     w.CB = Cp / CW;
@@ -461,10 +431,8 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
     w.splits = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
     floats[q] = (size_t)w.splits * pl->NB * w.CB * w.TG * w.JG * 1024;
   }
-  pl->db_rows = 64;
   pl->off_h = floats[0];
-  pl->off_db = floats[0] + floats[1];
-  pl->total_floats = floats[0] + floats[1] + (size_t)pl->db_rows * 4 * ly->Ch16;
+  pl->total_floats = floats[0] + floats[1];
   return NINT_OK;
 }
 
@@ -517,8 +485,8 @@ static int dispatch_wgrad(WgradArgs& a, const WgPart& w, int nblk, hipStream_t s
 }
 
 // Weight / bias gradients of several layers ("jobs") in one go: two MFMA launches per layer (x and h source) into
-// consecutive regions of ONE workspace, then ONE launch folds every split-K slab of every layer into its dW, one
-// launch column-sums all bias-gradient partial rows and one finishes them (12 launches -> 3 for a 3-layer model).
+// consecutive regions of ONE workspace, then ONE launch folds every split-K slab of every layer into its dW and db
+// (the x part's slabs carry the bias-gradient column).
 // h_skip: the first h_skip images have an identically zero h source (h_{-1} = 0 of a sequence that starts from
 // the zero state, model.py:259-262): the h part skips them -- 1/T of its work.
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
@@ -528,12 +496,9 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
   const int es = dtype == NINT_BF16 ? 2 : 4;
   hipStream_t st = (hipStream_t)stream;
   ReduceTable rt = {};
-  BiasTable bt = {};
-  bt.n = njobs;
   size_t off = 0;
   unsigned blk = 0;
-  int red_threads = 256, max_gc64 = 0, max_o64 = 0, db_rows_out = 64;
-  bool any_rows = false;
+  int red_threads = 256;
   for (int q = 0; q < njobs; ++q) {
     const WgJob& jb = jobs[q];
     const nint_layer* ly = jb.ly;
@@ -560,6 +525,7 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       a.partial = base + (part == 0 ? 0 : pl.off_h);
       a.CB = w.CB;
       a.NTC = w.NTC; a.J = w.J; a.TG = w.TG; a.JG = w.JG;
+      a.want_db = part == 0 ? 1 : 0;           // the x part sees every image (the h part may skip the first time step)
       a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * w.KX;
       a.P = g->P; a.Wh = g->Wh;
       a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
@@ -569,7 +535,7 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);
       if (rc != NINT_OK) return rc;
       ReduceEntry& E = rt.e[rt.n++];
-      E.part = a.partial; E.dW = jb.dW;
+      E.part = a.partial; E.dW = jb.dW; E.db = part == 0 ? jb.db : nullptr;
       E.Cx = ly->Cx; E.Ch = ly->Ch; E.Ch16 = ly->Ch16; E.k = ly->k; E.NB = pl.NB; E.CB = w.CB; E.NTC = w.NTC; E.J = w.J;
       E.splits = w.splits; E.is_h = part; E.xfold = ly->xfold; E.TG = w.TG; E.JG = w.JG;
       E.blk_begin = blk;
@@ -577,39 +543,15 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       E.waves = w.splits >= 64 ? 16 : 4;         // few large slabs: 4 waves share the splits; many small slabs: 16 waves
       if (E.waves * 64 > red_threads) red_threads = E.waves * 64;
     }
-    BiasEntry& B = bt.e[q];
-    B.partial = base + pl.off_db;              // (the region's tail is the scratch of the bias fold)
-    B.db = jb.db; B.ld = Gc; B.Ch = ly->Ch;
-    db_rows_out = pl.db_rows;
-    if (jb.db_partial) {
-      B.m = jb.db_partial; B.rows = jb.db_rows;
-      any_rows = true;
-    } else {                                   // no fused partial rows for this shape: a column-sum pass over dG
-      B.m = nullptr; B.rows = 0;
-      dim3 grid(pl.db_rows, Gc / 64);
-      if (dtype == NINT_BF16)
-        hipLaunchKernelGGL(colsum_partial_kernel<NINT_BF16>, grid, dim3(256), 0, st, jb.dG, B.partial, jb.N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
-      else
-        hipLaunchKernelGGL(colsum_partial_kernel<NINT_F32>, grid, dim3(256), 0, st, jb.dG, B.partial, jb.N, g->H, g->W, g->P, g->Hh, g->Wh, Gc);
-      NINT_LAUNCH_CHECK();
-    }
-    if (Gc / 64 > max_gc64) max_gc64 = Gc / 64;
-    if (nint_cdiv(4 * ly->Ch, 64) > max_o64) max_o64 = nint_cdiv(4 * ly->Ch, 64);
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blk), dim3(red_threads), 0, st, rt);
-  NINT_LAUNCH_CHECK();
-  if (any_rows) {
-    hipLaunchKernelGGL(rowsum_partial_kernel, dim3(max_gc64, db_rows_out, njobs), dim3(1024), 0, st, bt);
-    NINT_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(max_o64, njobs), dim3(1024), 0, st, bt, db_rows_out);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
 
 extern "C" int nint_conv_wgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG,
                                const void* x_slab, const void* h_slab, float* dW, float* db, float* partial,
-                               size_t partial_bytes, int n_cu, const float* db_partial, int db_rows, void* stream) {
-  const WgJob jb = {ly, N, dG, x_slab, h_slab, dW, db, db_partial, db_rows, 0};
+                               size_t partial_bytes, int n_cu, void* stream) {
+  const WgJob jb = {ly, N, dG, x_slab, h_slab, dW, db, 0};
   return nint_internal_conv_wgrad_multi(&jb, 1, g, dtype, partial, partial_bytes, n_cu, stream);
 }

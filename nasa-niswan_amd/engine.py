@@ -64,7 +64,7 @@ class Workspace:
         f32 = dict(dtype=torch.float32, device=dev)
         Cxp0 = eng.cfgs[0].padded(kc)[0]
         self.xs = torch.zeros(T * B * halo_px * Cxp0 * es, **u8)
-        self.h, self.c, self.gates, self.dG, self.dh, self.dc, self.dbp = [], [], [], [], [], [], []
+        self.h, self.c, self.gates, self.dG, self.dh, self.dc = [], [], [], [], [], []
         for cfg in eng.cfgs:
             Cxp, Ch16, Chp = cfg.padded(kc)
             self.h.append(torch.zeros((T + 1) * B * halo_px * Chp * es, **u8))
@@ -74,7 +74,6 @@ class Workspace:
                 self.dG.append(torch.zeros(T * B * halo_px * 4 * Ch16 * es, **u8))
                 self.dh.append(torch.zeros(B * comp_px * Chp * es, **u8))      # ET: transient gradient, read once per step
                 self.dc.append(torch.zeros(B * comp_px * Chp, **f32))
-                self.dbp.append(torch.zeros(T * _lib.NINT_DB_ROWS * 4 * Ch16, **f32))
         self.dx = None
         self.Cxp0 = Cxp0
         self.seq = NintSeq()
@@ -91,7 +90,6 @@ class Workspace:
                 s.dG[l] = self.dG[l].data_ptr()
                 s.dh[l] = self.dh[l].data_ptr()
                 s.dc[l] = self.dc[l].data_ptr()
-                s.db_partial[l] = self.dbp[l].data_ptr()
         if train:
             s.wg_partial = eng.wg_partial.data_ptr()
             s.wg_partial_bytes = eng.wg_partial.numel() * 4

@@ -1,0 +1,89 @@
+"""GPU: the fused BPTT step (nint_cell_bwd_fused: conv backward-data of time t+1 with the pointwise LSTM backward of
+time t in its epilogue) against the two separate launches it replaces (nint_conv_dgrad -> dh, nint_cell_bwd_pointwise),
+on the bench stack's three layers (8-row / 4-row tiles, 1-4 K-slices, x columns present and absent, ragged grids).
+f32: same arithmetic, only the association of dh = (h columns) + (x columns of the layer above) is shared -> 1e-6;
+bf16: the fused step keeps dh in f32 where the pair rounds it to bf16 in between -> rel-L2 1e-2 (the pair is the one
+further from the oracle)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import nasa_niswan_amd as p
+    p.load_library()
+    return p
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("H,W,B", [(100, 154, 2), (11, 19, 3), (8, 16, 1)])
+def test_fused_step_equals_dgrad_then_pointwise(pkg, dtype, H, W, B):
+    from nasa_niswan_amd.engine import LayerCfg, SeqEngine
+    lib = pkg.load_library()
+    torch.manual_seed(0)
+    hidden, ks, cin = (64, 32, 16), (5, 3, 3), 62
+    cfgs = []
+    for ch, k in zip(hidden, ks):
+        cfgs.append(LayerCfg(cin, ch, k)); cin = ch
+    eng = SeqEngine(cfgs, dtype, "cuda")
+    T = 2
+    ws = eng.acquire(B, T, H, W, True, False)
+    eng.pack_weights([torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * 0.05 for c in cfgs],
+                     [torch.randn(4 * c.Ch, device="cuda") * 0.1 for c in cfgs])
+    eng.forward(ws, torch.randn(B, T, 62, H, W, device="cuda"))
+    et = torch.bfloat16 if eng.es == 2 else torch.float32
+    g, es = C.byref(ws.g), eng.es
+    halo_px, comp_px = ws.g.Hh * ws.g.Wh, H * W
+    P = ws.g.P
+    for l, cfg in enumerate(cfgs):
+        ly = eng.layers[l]
+        Gc = 4 * ly.Ch16
+        # dG of time 1: random in the interior, zero halo (as the pointwise backward leaves it)
+        dG = ws.dG[l].view(et).view(T * B, ws.g.Hh, ws.g.Wh, Gc)
+        dG.zero_()
+        dG[B:, P:P + H, P:P + W] = (torch.randn(B, H, W, Gc, device="cuda") * 0.1).to(et)
+        dgs, gs, cs = B * halo_px * Gc * es, B * comp_px * Gc * es, B * comp_px * ly.Chp * 4
+        above = (torch.randn(B * comp_px * ly.Chp, device="cuda") * 0.1).to(et) if l < 2 else None
+        dc0 = torch.randn(B * comp_px * ly.Chp, device="cuda") * 0.1
+        vp = lambda t, off=0: C.c_void_p(t.data_ptr() + off)
+        # --- the pair
+        dh = torch.zeros(B * comp_px * ly.Chp, device="cuda", dtype=et)
+        dx_ref = torch.zeros(B * comp_px * ly.Cxp, device="cuda", dtype=et) if l > 0 else None
+        assert lib.nint_conv_dgrad(C.byref(ly), g, eng.dt, B, vp(ws.dG[l], dgs), vp(dx_ref) if l > 0 else None, vp(dh), None) == 0
+        if above is not None:
+            dh = (dh.float() + above.float()).to(et)
+        dc_ref = dc0.clone()
+        dG_ref = torch.zeros(B * halo_px * Gc, device="cuda", dtype=et)
+        assert lib.nint_cell_bwd_pointwise(C.byref(ly), g, eng.dt, B, vp(ws.gates[l]), vp(ws.c[l]), vp(ws.c[l], cs),
+                                           vp(dh), vp(dc_ref), vp(dG_ref), None) == 0
+        # --- fused
+        dc = dc0.clone()
+        dx = torch.full((B * comp_px * ly.Cxp,), 7.0, device="cuda", dtype=et) if l > 0 else None      # stored, not accumulated
+        assert lib.nint_cell_bwd_fused(C.byref(ly), g, eng.dt, B, vp(ws.dG[l], dgs), vp(dx) if l > 0 else None, vp(ws.gates[l]),
+                                       vp(ws.c[l]), vp(ws.c[l], cs), vp(above) if above is not None else None, vp(dc),
+                                       vp(ws.dG[l]), None) == 0
+        torch.cuda.synchronize()
+        dG_f = ws.dG[l].view(et)[:B * halo_px * Gc]
+        pairs = {"dG": (dG_f, dG_ref), "dc": (dc, dc_ref)}
+        if l > 0:
+            pairs["dx"] = (dx, dx_ref)
+        for name, (a, b) in pairs.items():
+            a, b = a.double(), b.double()
+            assert torch.isfinite(a).all(), (l, name)
+            if dtype == "f32" or name == "dx":
+                err, ref = float((a - b).abs().max()), float(b.abs().max())
+                assert err <= 1e-6 * ref + 1e-9, (l, name, err, ref)
+            else:
+                r = float((a - b).norm() / b.norm())
+                assert r <= 1e-2, (l, name, r)
+        # the halo ring of the dG slab stays zero
+        d4 = dG_f.view(B, ws.g.Hh, ws.g.Wh, Gc).float()
+        assert float(d4[:, :P].abs().max()) == 0 and float(d4[:, :, :P].abs().max()) == 0
+        assert float(d4[:, P + H:].abs().max()) == 0 and float(d4[:, :, P + W:].abs().max()) == 0

@@ -54,6 +54,13 @@ def main():
                                      C.c_void_p(ws.c[l].data_ptr() + 2 * cs), C.c_void_p(ws.gates[l].data_ptr() + gs), None) == 0
         nsteps = (ly.Cxp + ly.Chp) // 32 * ly.k ** 2
         mfma_per_step = None
+    elif args.kernel.startswith("fused"):
+        dx = ws.dh[l - 1].data_ptr() if l > 0 else None
+        def fn():
+            assert lib.nint_cell_bwd_fused(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.dG[l].data_ptr() + dgs), C.c_void_p(dx) if dx else None,
+                                           C.c_void_p(ws.gates[l].data_ptr()), C.c_void_p(ws.c[l].data_ptr()),
+                                           C.c_void_p(ws.c[l].data_ptr() + cs), C.c_void_p(ws.dh[l].data_ptr()) if l < 2 else None,
+                                           C.c_void_p(ws.dc[l].data_ptr()), C.c_void_p(ws.dG[l].data_ptr()), None) == 0
     else:
         dx = ws.dh[l - 1].data_ptr() if l > 0 else None
         def fn():

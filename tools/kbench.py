@@ -101,7 +101,7 @@ def main():
             assert lib.nint_cell_bwd_pointwise(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.gates[l].data_ptr() + gs),
                                                C.c_void_p(ws.c[l].data_ptr() + cs), C.c_void_p(ws.c[l].data_ptr() + 2 * cs),
                                                C.c_void_p(ws.dh[l].data_ptr()), C.c_void_p(ws.dc[l].data_ptr()),
-                                               C.c_void_p(ws.dG[l].data_ptr() + dgs), C.c_void_p(ws.dbp[l].data_ptr()), st) == 0
+                                               C.c_void_p(ws.dG[l].data_ptr() + dgs), st) == 0
         run(f"pointwise{l}", pw, None, B * comp_px * ly.Ch16 * (9 * es + 16))   # gates+dG (ET), dh (ET), c_prev, c_new, dc r+w (f32)
     # fill dG for every t so that wgrad sees random data
     for l in range(3):
@@ -117,6 +117,14 @@ def main():
             assert lib.nint_conv_dgrad(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.dG[l].data_ptr() + dgs),
                                        C.c_void_p(dx) if dx else None, C.c_void_p(ws.dh[l].data_ptr()), st) == 0
         run(f"dgrad{l}", dg, fl)
+        gs, cs = B * comp_px * 4 * ly.Ch16 * es, B * comp_px * ly.Chp * 4
+
+        def fused(ly=ly, dgs=dgs, dx=dx, l=l, gs=gs, cs=cs):      # dgrad(t+1) + pointwise backward(t) in one launch
+            assert lib.nint_cell_bwd_fused(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.dG[l].data_ptr() + dgs), C.c_void_p(dx) if dx else None,
+                                           C.c_void_p(ws.gates[l].data_ptr() + gs), C.c_void_p(ws.c[l].data_ptr() + cs),
+                                           C.c_void_p(ws.c[l].data_ptr() + 2 * cs), C.c_void_p(ws.dh[l].data_ptr()) if l < 2 else None,
+                                           C.c_void_p(ws.dc[l].data_ptr()), C.c_void_p(ws.dG[l].data_ptr()), st) == 0
+        run(f"fused{l}", fused, fl)
         dW = torch.empty(4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k, device="cuda")
         db = torch.empty(4 * cfg.Ch, device="cuda")
         x_all = ws.xs.data_ptr() if l == 0 else ws.h[l - 1].data_ptr() + B * halo_px * ly.Cxp * es
@@ -125,8 +133,7 @@ def main():
         def wg(ly=ly, x_all=x_all, dW=dW, db=db, l=l):
             assert lib.nint_conv_wgrad(C.byref(ly), g, eng.dt, T * B, C.c_void_p(ws.dG[l].data_ptr()), C.c_void_p(x_all),
                                        C.c_void_p(ws.h[l].data_ptr()), C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()),
-                                       C.c_void_p(eng.wg_partial.data_ptr()), eng.wg_partial.numel() * 4, eng.n_cu,
-                                       C.c_void_p(ws.dbp[l].data_ptr()), T * 1024, st) == 0
+                                       C.c_void_p(eng.wg_partial.data_ptr()), eng.wg_partial.numel() * 4, eng.n_cu, st) == 0
         run(f"wgrad{l}", wg, flw)
     xs_pack = lambda: lib.nint_pack_btchw(C.c_void_p(X.data_ptr()), C.c_void_p(ws.xs.data_ptr()), B, T, args.C, ws.Cxp0, g, eng.dt, st)
     run("pack", xs_pack, None, X.numel() * 4 + B * T * comp_px * ws.Cxp0 * es)
