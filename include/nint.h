@@ -95,6 +95,9 @@ typedef struct nint_seq {
   float* wg_partial;                   /* f32 split-K slabs for wgrad: the SUM over the layers of nint_wgrad_workspace_bytes
                                         * (each rounded up to 256 bytes) -- the layers' slabs sit side by side */
   size_t wg_partial_bytes;
+  int32_t fuse_bwd;                    /* backward schedule: 0 = per layer (fused BPTT step for the short-K layers), 1 = never
+                                        * fused, 2 = every layer fused (nint_cell_bwd_fused; same results up to the bf16
+                                        * rounding of the intermediate dh, which the fused step skips) */
 } nint_seq;
 
 /* ---- library / device ---------------------------------------------------------------- */

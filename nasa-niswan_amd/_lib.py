@@ -35,7 +35,7 @@ class NintSeq(C.Structure):
                 ("xs", vp), ("h", vp * NINT_MAX_LAYERS), ("c", vp * NINT_MAX_LAYERS),
                 ("gates", vp * NINT_MAX_LAYERS), ("dG", vp * NINT_MAX_LAYERS), ("dh", vp * NINT_MAX_LAYERS),
                 ("dc", vp * NINT_MAX_LAYERS), ("dx", vp), ("dW", vp * NINT_MAX_LAYERS), ("db", vp * NINT_MAX_LAYERS),
-                ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t)]
+                ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t), ("fuse_bwd", C.c_int32)]
 
 
 # every symbol include/nint.h declares: name -> (restype, argtypes)

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     // HBM-bound pass (34 bytes per channel-pixel) hides behind the matrix work of the CU's other workgroup.
     //   dct = dc + dh*o*(1 - tanh(c_t)^2);  dG = (dct*g*i(1-i), dct*c_{t-1}*f(1-f), dct*i*(1-g^2), dh*tanh(c_t)*o(1-o))
     //   dc <- dct*f                                                     (autograd of model.py:222-229)
-    // x columns are STORED: in the fused schedule they are the only writer of their destination.
+    // x columns are stored, or accumulated onto what a classic layer below keeps in its dh buffer (out0_overwrite).
     // All loads of a batch of rows are issued before its first store (vmcnt retires in order and counts stores).
     typedef Pk4<DT> PK;
     const int Gc = 4 * a.Ch16;
@@ -547,7 +547,9 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
           for (int q = 0; q < 4; ++q) gq[ii][j][q] = PK::zero();
           oldv[ii][j] = PK::zero();
           cpq[ii][j] = cnq[ii][j] = dcq[ii][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          if (hch >= 0 && hch < a.Ch16 && okp) {
+          if (hch < 0) {                                          // x columns accumulating onto a classic layer's h columns
+            if (a.out0 && !a.out0_overwrite && okp) oldv[ii][j] = PK::ld(a.out0, rowpix * a.C0p + (unsigned)(x * a.C0p + (nt0 + j) * 16 + c4));
+          } else if (hch < a.Ch16 && okp) {
             const size_t pix = rowpix + x;
             const size_t gb = pix * Gc + (size_t)(hch >> 4) * 64 + c4;
 #pragma unroll
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
           const int n = (nt0 + j) * 16 + c4;
           const int hch = (nt0 + j) * 16 - a.C0p;
           if (hch < 0) {
-            if (a.out0 && okp) store_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + n), acc[i][j]);
+            if (a.out0 && okp) store_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + n), acc[i][j] + PK::up(oldv[ii][j]));
           } else if (hch < a.Ch16 && okp) {
             const f32x4_t gi = PK::up(gq[ii][j][0]), gf = PK::up(gq[ii][j][1]), gg = PK::up(gq[ii][j][2]), go = PK::up(gq[ii][j][3]);
             const f32x4_t dhv = acc[i][j] + PK::up(oldv[ii][j]);

@@ -146,27 +146,58 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   if (s->need_dx && !s->dx) return NINT_E_ARG;
   if (!s->wg_partial) return NINT_E_ARG;
 
-  for (int t = s->T - 1; t >= 0; --t) {
+  // BPTT.  A layer runs either the CLASSIC step (pointwise backward of time u, then conv backward-data of time u) or the
+  // FUSED step X[u] = conv backward-data of time u with the pointwise backward of time u-1 in its epilogue
+  // (nint_cell_bwd_fused: d/dh_{u-1} never goes to memory; chosen for the short-K narrow layers, where it is faster than
+  // the pair -- measured; the wide layer keeps the pair).  A fused layer consumes the x columns that the layer above
+  // produced for time u-1, so it runs ONE time step behind the layer above: at outer step s layer l works on time
+  // u_l = s + off_l, off_l = number of fused layers among l..L-1.  Fused layer: u = T -> pointwise backward of T-1 alone
+  // (d/dh_{T-1} comes from the head / the caller), 1 <= u <= T-1 -> X[u], u = 0 -> plain conv backward-data of time 0.
+  bool fused[NINT_MAX_LAYERS];
+  int off[NINT_MAX_LAYERS];
+  for (int l = L - 1; l >= 0; --l) {
+    const nint_layer* ly = &s->layer[l];
+    const int ksteps = (4 * ly->Ch16 / (s->dtype == NINT_BF16 ? 32 : 16)) * ly->k * ly->k;   // K-steps of the layer's dgrad launch
+    fused[l] = s->fuse_bwd == 2 || (s->fuse_bwd == 0 && ksteps <= 64);
+    off[l] = (l == L - 1 ? 0 : off[l + 1]) + (fused[l] ? 1 : 0);
+  }
+  const int T = s->T;
+  for (int so = T - 1; so >= -off[0]; --so) {
     for (int l = L - 1; l >= 0; --l) {
+      const int u = so + off[l];
+      if (u < 0 || u > (fused[l] ? T : T - 1)) continue;
       const nint_layer* ly = &s->layer[l];
       const size_t cs = (size_t)B * comp_px * ly->Chp;
       const size_t Gc = 4 * (size_t)ly->Ch16;
-      const char* gates = (const char*)s->gates[l] + (size_t)t * B * comp_px * Gc * es;
-      char* dG = (char*)s->dG[l] + (size_t)t * B * halo_px * Gc * es;
+      const size_t gs = (size_t)B * comp_px * Gc * es, dgs = (size_t)B * halo_px * Gc * es;
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
-      // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
-      const bool first = t == s->T - 1;
-      rc = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, gates, s->c[l] + (size_t)t * cs, s->c[l] + (size_t)(t + 1) * cs,
-                                            s->dh[l], s->dc[l], dG, first && ((s->zero_dstate >> (2 * l)) & 1), stream);
-      if (rc != NINT_OK) return rc;
-      void* dx_accum = (l > 0) ? s->dh[l - 1]
-                               : (s->need_dx ? (void*)((char*)s->dx + (size_t)t * B * comp_px * ly->Cxp * es) : nullptr);
-      // at t == 0 with a zero initial state nobody consumes d/dh_{-1}
-      void* dh_prev = (t == 0 && !s->has_init_state) ? nullptr : s->dh[l];
-      // the x columns overwrite instead of accumulate where the destination is known to be zero: dx (every time
-      // step has its own slab, written once) and, at the first step, a dh[l-1] flagged zero
-      const bool ow = l == 0 ? true : (first && ((s->zero_dstate >> (2 * (l - 1) + 1)) & 1));
-      rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, dG, dx_accum, dh_prev, ow, nullptr, stream);
+      auto pointwise = [&](int t) {      // consumes dh[l] / dc[l] of time t, writes dG of time t
+        // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
+        return nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, (const char*)s->gates[l] + (size_t)t * gs, s->c[l] + (size_t)t * cs,
+                                                s->c[l] + (size_t)(t + 1) * cs, s->dh[l], s->dc[l], (char*)s->dG[l] + (size_t)t * dgs,
+                                                t == T - 1 && ((s->zero_dstate >> (2 * l)) & 1), stream);
+      };
+      // destination of the x columns of time t: the layer below's dh, or this time step's dx slab (written once)
+      void* dx_dst = (l > 0) ? s->dh[l - 1]
+                             : (s->need_dx ? (void*)((char*)s->dx + (size_t)u * B * comp_px * ly->Cxp * es) : nullptr);
+      // ... stored where nothing else is there: dx; a dh flagged zero at the first step; a FUSED layer below (its dh
+      // buffer only ever carries these columns).  Accumulated onto the h columns a classic layer below stored.
+      const bool ow = l == 0 ? true : (u == T - 1 ? (((s->zero_dstate >> (2 * (l - 1) + 1)) & 1) != 0) : fused[l - 1]);
+      // at time 0 with a zero initial state nobody consumes d/dh_{-1}
+      void* dh_prev = (u == 0 && !s->has_init_state) ? nullptr : s->dh[l];
+      if (!fused[l]) {
+        rc = pointwise(u);
+        if (rc != NINT_OK) return rc;
+        rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, nullptr, stream);
+      } else if (u == T) {
+        rc = pointwise(T - 1);
+      } else if (u >= 1) {
+        const DgradPw pw = {(const char*)s->gates[l] + (size_t)(u - 1) * gs, s->c[l] + (size_t)(u - 1) * cs, s->c[l] + (size_t)u * cs,
+                            s->dc[l], l < L - 1 ? s->dh[l] : nullptr, (char*)s->dG[l] + (size_t)(u - 1) * dgs};
+        rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream);
+      } else {
+        rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l], dx_dst, dh_prev, ow, nullptr, stream);
+      }
       if (rc != NINT_OK) return rc;
     }
   }

@@ -19,6 +19,7 @@ FORCE_TILE_ROWS = 0
 # when that lowers the number of MFMA K-steps (nint_xfold_pays): 5 x-steps instead of 25.  False keeps the plain
 # channel-padded layout for engines built afterwards (tests run both).
 XFOLD = True
+FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
 
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
 
@@ -80,6 +81,7 @@ class Workspace:
         s = self.seq
         s.dtype, s.B, s.T, s.L = eng.dt, B, T, len(eng.cfgs)
         s.need_dx, s.has_init_state, s.n_cu = 0, int(has_init), eng.n_cu
+        s.fuse_bwd = FUSE_BWD
         s.g = g
         s.xs = self.xs.data_ptr()
         for l in range(len(eng.cfgs)):

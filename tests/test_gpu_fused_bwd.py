@@ -87,3 +87,44 @@ def test_fused_step_equals_dgrad_then_pointwise(pkg, dtype, H, W, B):
         d4 = dG_f.view(B, ws.g.Hh, ws.g.Wh, Gc).float()
         assert float(d4[:, :P].abs().max()) == 0 and float(d4[:, :, :P].abs().max()) == 0
         assert float(d4[:, P + H:].abs().max()) == 0 and float(d4[:, :, P + W:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_backward_schedules_keep_parity(pkg, mode):
+    """nint_seq.fuse_bwd: 1 = every layer runs the classic pair, 2 = every layer runs the fused step, one time step behind
+    the layer above (the default, 0, mixes them per layer and is what the rest of the suite runs).  Every gradient, the
+    input gradient included, against the oracle on ragged / multi-layer / reference-size shapes, T = 1 .. 3."""
+    from nasa_niswan_amd import engine
+    from test_gpu_shapes import CASES, check, run_case
+    engine.FUSE_BWD = mode
+    try:
+        for name in ("ragged-grid-odd-channels", "batch1-T1", "k1-and-k3", "wide-hidden-48"):
+            for dtype in ("f32", "bf16"):
+                check(run_case(pkg, *CASES[name], dtype), dtype)
+        check(run_case(pkg, 5, [64, 32, 16], [5, 3, 3], 1, 2, 3, 20, 36, "f32"), "f32")        # the reference stack, T = 3
+        check(run_case(pkg, 62, [64, 32, 16], [5, 3, 3], 20, 1, 2, 100, 154, "bf16"), "bf16")  # bench geometry, T = 2
+        check(run_case(pkg, 6, [128, 128], [3, 3], 1, 1, 2, 10, 18, "bf16"), "bf16")           # several column groups per launch
+    finally:
+        engine.FUSE_BWD = 0
+
+
+def test_fused_and_classic_schedules_agree(pkg):
+    """Same model and inputs through both schedules, f32: every gradient (input gradient included) agrees to rounding."""
+    from nasa_niswan_amd import engine
+    torch.manual_seed(3)
+    C_, hidden, ks, B, T, H, W = 6, [16, 8], [3, 3], 2, 3, 12, 20
+    X = torch.randn(B, T, C_, H, W, device="cuda")
+    wgt = torch.randn(B, 1, H, W, device="cuda")
+    res = {}
+    for mode in (1, 2):
+        engine.FUSE_BWD = mode
+        try:
+            torch.manual_seed(4)
+            net = pkg.ConvLSTM(C_, hidden, ks, 2).cuda()
+            Xg = X.clone().requires_grad_(True)
+            (net(Xg) * wgt).sum().backward()
+            res[mode] = [Xg.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        finally:
+            engine.FUSE_BWD = 0
+    for a, b in zip(res[1], res[2]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
