@@ -148,8 +148,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
 
   // BPTT.  A layer runs either the CLASSIC step (pointwise backward of time u, then conv backward-data of time u) or the
   // FUSED step X[u] = conv backward-data of time u with the pointwise backward of time u-1 in its epilogue
-  // (nint_cell_bwd_fused: d/dh_{u-1} never goes to memory; chosen for the short-K narrow layers, where it is faster than
-  // the pair -- measured; the wide layer keeps the pair).  A fused layer consumes the x columns that the layer above
+  // (nint_cell_bwd_fused: d/dh_{u-1} never goes to memory).  Chosen per layer by the K-steps of its dgrad launch:
+  // measured inside the bench step on two devices (bench.py --fuse-bwd 16+mask), fusing the 18-step top layer alone gives
+  // +0.7 ... +1.0 %, the 36-step layer -0.9 %, the 200-step layer -1.7 % (its workgroups run their phases in lockstep, so
+  // the heavier epilogue adds its full HBM time instead of hiding behind the other workgroup's matrix work).  A fused layer consumes the x columns that the layer above
   // produced for time u-1, so it runs ONE time step behind the layer above: at outer step s layer l works on time
   // u_l = s + off_l, off_l = number of fused layers among l..L-1.  Fused layer: u = T -> pointwise backward of T-1 alone
   // (d/dh_{T-1} comes from the head / the caller), 1 <= u <= T-1 -> X[u], u = 0 -> plain conv backward-data of time 0.
@@ -158,7 +160,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   for (int l = L - 1; l >= 0; --l) {
     const nint_layer* ly = &s->layer[l];
     const int ksteps = (4 * ly->Ch16 / (s->dtype == NINT_BF16 ? 32 : 16)) * ly->k * ly->k;   // K-steps of the layer's dgrad launch
-    fused[l] = s->fuse_bwd == 2 || (s->fuse_bwd == 0 && ksteps <= 64);
+    fused[l] = s->fuse_bwd >= 16 ? ((s->fuse_bwd >> l) & 1) != 0 : (s->fuse_bwd == 2 || (s->fuse_bwd == 0 && ksteps <= 24));
     off[l] = (l == L - 1 ? 0 : off[l + 1]) + (fused[l] ? 1 : 0);
   }
   const int T = s->T;
