@@ -47,11 +47,22 @@ constexpr int BD_NARROW = 2;       // 4-row tiles: three workgroups per CU hide 
 // their own that no kernel reads; the shipped library is built without NINT_STAMP.
 #define NINT_STAMP_WGS 4096
 __device__ unsigned long long g_stamp[NINT_STAMP_WGS * 8];
+__device__ unsigned g_hwid[NINT_STAMP_WGS * 2];      // HW_ID (wave / SIMD / CU / SH / SE ids) and XCC_ID of each workgroup's first wave
 #define NINT_STAMP_AT(slot)                                                              \
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < NINT_STAMP_WGS) {                      \
     g_stamp[blockIdx.x * 8 + 2 * (slot)] = __builtin_amdgcn_s_memtime();                 \
     g_stamp[blockIdx.x * 8 + 2 * (slot) + 1] = __builtin_amdgcn_s_memrealtime();         \
+    if ((slot) == 0) {                                                                   \
+      g_hwid[blockIdx.x * 2] = __builtin_amdgcn_s_getreg(4 | (31 << 11));                \
+      g_hwid[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_getreg(20 | (3 << 11));            \
+    }                                                                                    \
   }
+extern "C" int nint_debug_read_hwid(unsigned* host, int n_wgs) {
+  if (!host || n_wgs <= 0 || n_wgs > NINT_STAMP_WGS) return NINT_E_ARG;
+  NINT_CHECK_HIP(hipDeviceSynchronize());
+  NINT_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hwid), (size_t)n_wgs * 2 * sizeof(unsigned)));
+  return NINT_OK;
+}
 extern "C" int nint_debug_read_stamps(unsigned long long* host, int n_wgs) {
   if (!host || n_wgs <= 0 || n_wgs > NINT_STAMP_WGS) return NINT_E_ARG;
   NINT_CHECK_HIP(hipDeviceSynchronize());

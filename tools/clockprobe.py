@@ -104,6 +104,24 @@ def main():
     grid = np.linspace(0, end.max(), 25)
     k0, k1 = (rt[:, 1] - t0) / 100.0, (rt[:, 2] - t0) / 100.0
     print("  workgroups inside K loop at t:", " ".join(f"{int(((k0 <= t) & (k1 > t)).sum())}" for t in grid))
+    if hasattr(lib, "nint_debug_read_hwid"):
+        # which workgroups share a CU: HW_ID = wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; XCC_ID[3:0]
+        hw = np.zeros(nw * 2, dtype=np.uint32)
+        lib.nint_debug_read_hwid.restype, lib.nint_debug_read_hwid.argtypes = C.c_int, [C.c_void_p, C.c_int]
+        assert lib.nint_debug_read_hwid(hw.ctypes.data, nw) == 0
+        hw = hw.reshape(nw, 2)[:len(used)][used]
+        hw = hw[:len(st)] if len(hw) != len(st) else hw
+        cu = ((hw[:, 1] & 15).astype(np.int64) << 8) | (((hw[:, 0] >> 13) & 7).astype(np.int64) << 5) | (((hw[:, 0] >> 12) & 1).astype(np.int64) << 4) | ((hw[:, 0] >> 8) & 15)
+        order = np.argsort(start, kind="stable")
+        first = order[:512] if len(order) >= 512 else order
+        print("  distinct CUs seen:", len(set(cu.tolist())), " first 24 workgroups -> (xcc, se, sh, cu):",
+              " ".join(f"{int(hw[b, 1] & 15)}.{int((hw[b, 0] >> 13) & 7)}.{int((hw[b, 0] >> 12) & 1)}.{int((hw[b, 0] >> 8) & 15)}" for b in range(24)))
+        pairs = {}
+        for b in first:
+            pairs.setdefault(int(cu[b]), []).append(int(b))
+        diffs = [p[1] - p[0] for p in pairs.values() if len(p) == 2]
+        vals, cnts = np.unique(diffs, return_counts=True)
+        print("  first-round workgroups sharing a CU: blockIdx difference histogram:", " ".join(f"{v}:{c}" for v, c in zip(vals, cnts)))
     print("  workgroups in fill/epilogue at t:", " ".join(f"{int((((start <= t) & (k0 > t)) | ((k1 <= t) & (end > t))).sum())}" for t in grid))
 
 
