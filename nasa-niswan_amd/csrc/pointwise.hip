@@ -666,54 +666,52 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const void* __restrict
   }
 }
 
-// Fast path for small heads (O*(Ch+1) <= 512 outputs): every workgroup owns a pixel range, stages
-// 64 pixels of dpred and h in LDS at a time, thread (o, c) accumulates its own output over the
-// range; per-workgroup partials are folded in fixed order by head_bwd_dw_final_kernel.
-#define HEAD_DW_BLOCKS 256
+// Fast path for small heads (O*(Ch+1) <= 512 outputs): every workgroup owns a pixel range, stages HEAD_DW_PIX pixels of
+// dpred and h in LDS at a time (ONE HBM round trip per 240 pixels: the launch is latency-bound, 14 MB in all), thread
+// (o, c) accumulates its own output over the range; per-workgroup partials are folded in fixed order by
+// head_bwd_dw_final_kernel.  The grid is one workgroup per HEAD_DW_PIX pixels, as far as the caller's scratch goes.
+#define HEAD_DW_PIX 240
 template <int DT>
 __global__ __launch_bounds__(512) void head_bwd_dw_tiled_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp,
                                                               int O, const float* __restrict__ dpred,
                                                               float* __restrict__ partial, int H, int W, int P, int Hh,
                                                               int Wh) {
-  __shared__ float sd[64 * 33];                // [pixel][o] (O <= 32), padded
-  __shared__ float sh[64 * 33];                // [pixel][c] (Ch <= 32) + a constant 1 for the bias column
+  __shared__ float sd[HEAD_DW_PIX * 33];       // [pixel][o] (O <= 32), padded
+  __shared__ float sh[HEAD_DW_PIX * 33];       // [pixel][c] (Ch <= 32) + a constant 1 for the bias column
   const int nout = O * (Ch + 1);
   const int o = threadIdx.x / (Ch + 1), c = threadIdx.x % (Ch + 1);
   const size_t npix = (size_t)N * H * W;
   const size_t per = (npix + gridDim.x - 1) / gridDim.x;
   const size_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  const int nq = (Ch + 3) / 4;                 // channel quads of a pixel (Chp is a multiple of 16: the vector load stays inside)
   float acc = 0.f;
-  for (size_t base = p0; base < p1; base += 64) {
-    const int cnt = (int)min((size_t)64, p1 - base);
+  for (size_t base = p0; base < p1; base += HEAD_DW_PIX) {
+    const int cnt = (int)min((size_t)HEAD_DW_PIX, p1 - base);
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * O; i += 512) {
-      const int oo = i / 64, pp = i % 64;
-      float v = 0.f;
-      if (pp < cnt) {
-        const size_t pix = base + pp;
-        const size_t yx = pix % ((size_t)H * W);
-        const size_t n = pix / ((size_t)H * W);
-        v = dpred[(n * O + oo) * (size_t)H * W + yx];
-      }
-      sd[pp * 33 + oo] = v;
+    for (int i = threadIdx.x; i < cnt * O; i += 512) {        // dpred planes: consecutive threads walk consecutive pixels
+      const int oo = i / cnt, pp = i - oo * cnt;
+      const size_t pix = base + pp;
+      const size_t yx = pix % ((size_t)H * W);
+      const size_t n = pix / ((size_t)H * W);
+      sd[pp * 33 + oo] = dpred[(n * O + oo) * (size_t)H * W + yx];
     }
-    for (int i = threadIdx.x; i < 64 * (Ch + 1); i += 512) {
-      const int pp = i / (Ch + 1), cc = i % (Ch + 1);
-      float v = 0.f;
-      if (pp < cnt) {
-        const size_t pix = base + pp;
-        const int x = pix % W;
-        size_t r = pix / W;
-        const int y = r % H;
-        const int n = r / H;
-        v = cc < Ch ? load_elem<DT>(h, ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp + cc) : 1.f;
-      }
-      sh[pp * 33 + cc] = v;
+    for (int i = threadIdx.x; i < cnt * nq; i += 512) {       // h: one 4-channel vector per thread
+      const int pp = i / nq, q = i - pp * nq;
+      const size_t pix = base + pp;
+      const int x = pix % W;
+      size_t r = pix / W;
+      const int y = r % H;
+      const int n = r / H;
+      const f32x4_t v = load_vec4<DT>(h, ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < Ch) sh[pp * 33 + 4 * q + e] = v[e];
+      if (q == 0) sh[pp * 33 + Ch] = 1.f;
     }
     __syncthreads();
     if ((int)threadIdx.x < nout) {
 #pragma unroll 8
-      for (int pp = 0; pp < 64; ++pp) acc += sd[pp * 33 + o] * sh[pp * 33 + c];
+      for (int pp = 0; pp < cnt; ++pp) acc += sd[pp * 33 + o] * sh[pp * 33 + c];
     }
   }
   if ((int)threadIdx.x < nout) partial[(size_t)blockIdx.x * nout + threadIdx.x] = acc;
@@ -766,8 +764,8 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   if (!h_slab || !w || !dpred || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const size_t npix = (size_t)N * g->H * g->W;
   if (dh) {
-    const size_t npix = (size_t)N * g->H * g->W;
     const dim3 gp((unsigned)((npix + 255) / 256));
     const bool b16 = dtype == NINT_BF16;
     if (Chp <= 32 && Chp % 4 == 0) {
@@ -783,14 +781,16 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
     NINT_LAUNCH_CHECK();
   }
   const int nout = O * (Ch + 1);
-  if (dw && db && scratch && nout <= 512 && O <= 32 && Ch <= 32 &&
-      scratch_bytes >= (size_t)HEAD_DW_BLOCKS * nout * sizeof(float)) {
+  if (dw && db && scratch && nout <= 512 && O <= 32 && Ch <= 32 && scratch_bytes >= (size_t)256 * nout * sizeof(float)) {
+    const size_t cap = scratch_bytes / ((size_t)nout * sizeof(float));
+    const size_t want = (npix + HEAD_DW_PIX - 1) / HEAD_DW_PIX;
+    const int nblk = (int)(want < cap ? want : cap);
     if (dtype == NINT_BF16)
-      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_BF16>, dim3(HEAD_DW_BLOCKS), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
+      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_BF16>, dim3(nblk), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
     else
-      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_F32>, dim3(HEAD_DW_BLOCKS), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
+      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_F32>, dim3(nblk), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
     NINT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(nint_cdiv(nout, 64)), dim3(1024), 0, st, scratch, HEAD_DW_BLOCKS, Ch, O, dw, db);
+    hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(nint_cdiv(nout, 64)), dim3(1024), 0, st, scratch, nblk, Ch, O, dw, db);
     NINT_LAUNCH_CHECK();
   } else if (dw && db) {
     if (dtype == NINT_BF16)
@@ -923,8 +923,8 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
     float* dp = dpred + ((size_t)n * O * H + yy) * W + x;
     const float* yp = y + ((size_t)n * O * Hc + cy) * Wc + cx;
     // the targets of OU outputs are fetched before they are used: one dependent HBM round trip per OU outputs instead
-    // of one per output (the sums below still run in output order)
-    constexpr int OU = 4;
+    // of one per output (the sums below still run in output order); 20 outputs = one trip
+    constexpr int OU = 20;
     for (int o0 = 0; o0 < O; o0 += OU) {
       float tq[OU];
 #pragma unroll
