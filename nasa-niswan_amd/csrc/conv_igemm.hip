@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef NINT_EXPERIMENT
-  if (EPI == EPI_DGRAD_PW && (a.dbg >> 8) && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1)) {
+  if (MT >= 8 && (a.dbg >> 8) && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1)) {
     // stagger experiment: the second workgroup of each CU starts (dbg >> 8) microseconds late
     const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + 100ull * (a.dbg >> 8);
     while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(32);
