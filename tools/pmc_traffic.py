@@ -10,7 +10,7 @@ KEYS = {   # kernel-name prefix in the summary -> (bench key, launches of that k
     "void conv_igemm_kernel<1, 0, 4, 1, 4, 8>": ("conv_igemm_fwd_layer0", 1),
     "void conv_igemm_kernel<1, 1, 1, 4, 4, 8>": ("conv_igemm_dgrad_layer0", 1),
     "void wgrad_kernel<1, 7, 1, 5, 1, 5>": ("wgrad_layer0", 2),          # x part + h part
-    "void lstm_bwd_pointwise_kernel<1, true>": ("lstm_bwd_pointwise_layer0", 1),
+    "void lstm_bwd_pointwise_kernel<1>": ("lstm_bwd_pointwise_layer0", 1),
 }
 txt = open(sys.argv[1]).read()
 out = {"_comment": "HBM traffic per launch from rocprofv3 --pmc passes (tools/pmc.sh over tools/kbench.py, FETCH_SIZE and WRITE_SIZE in "
