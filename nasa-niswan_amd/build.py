@@ -17,6 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnint_hip.so")
 SOURCES = ["conv_igemm.hip", "wgrad.hip", "pointwise.hip", "seq.hip"]
+EXP_SOURCES = ["conv_ws.hip"]      # experiment build only (tools/kbench.py --exp --dbg 0x1000): measured, not shipped
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wall", "-Wno-unused-variable", "-Wno-unused-local-typedef"]
@@ -36,7 +37,7 @@ def build(force: bool = False, verbose: bool = False, exp: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "nint_common.h"), os.path.join(ROOT, "include", "nint.h")]
     objs, jobs = [], []
-    for src in SOURCES:
+    for src in SOURCES + (EXP_SOURCES if exp else []):
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(op)

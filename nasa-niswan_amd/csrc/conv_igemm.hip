@@ -767,6 +767,12 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.tile_rows = ly->tile_rows & 0xff;
 #endif
   hipStream_t st = (hipStream_t)stream;
+#ifdef NINT_EXPERIMENT
+  if (dtype == NINT_BF16 && (a.dbg & 0x1000)) {   // experiment build: weight-stationary persistent kernel for the narrow layers (conv_ws.hip)
+    const int rc = nint_internal_conv_ws_lstm(a, N, stream);
+    if (rc != NINT_E_SHAPE) return rc;
+  }
+#endif
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st);
 }

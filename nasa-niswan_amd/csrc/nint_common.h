@@ -167,6 +167,8 @@ struct WgJob {           // one layer's weight / bias gradient
 };
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
                                    size_t partial_bytes, int n_cu, void* stream);
+// weight-stationary persistent gate kernel for the narrow layers (conv_ws.hip); NINT_E_SHAPE = not served, take the streaming kernel
+int nint_internal_conv_ws_lstm(ConvArgs& a, int N, void* stream);
 struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
 };

@@ -145,6 +145,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     if (!s->gates[l] || !s->dG[l] || !s->dh[l] || !s->dc[l] || !s->dW[l] || !s->db[l]) return NINT_E_ARG;
   if (s->need_dx && !s->dx) return NINT_E_ARG;
   if (!s->wg_partial) return NINT_E_ARG;
+  if (s->fuse_bwd < 0 || (s->fuse_bwd > 2 && s->fuse_bwd < 16) || s->fuse_bwd >= 16 + (1 << NINT_MAX_LAYERS)) return NINT_E_ARG;
 
   // BPTT.  A layer runs either the CLASSIC step (pointwise backward of time u, then conv backward-data of time u) or the
   // FUSED step X[u] = conv backward-data of time u with the pointwise backward of time u-1 in its epilogue
