@@ -23,16 +23,25 @@
 #include <type_traits>
 #include "nint_common.h"
 
-struct WgradArgs {
-  const char* dG; long dG_img_stride; int dG_pix_stride;
+struct WgSrc {           // one source (x or h) of a launch
+  const char* dG;        // first image of this source's reduction (the h source may skip the zero-state time step)
   const char* src; long src_img_stride; int src_pix_stride;
   float* partial;
-  int CB, NTC, J;        // channel blocks, channel tiles per block, (tap, channel-tile) columns in all
-  int TG, JG;            // column groups of 4*JW columns (49 taps of a 7x7 kernel: 2) and columns per block slab
+  int CB, JG;            // channel blocks; columns per block slab (the x source's slabs carry the bias-gradient column)
+  int nblk;              // workgroup columns of this source: NB * CB * TG
+  int ntiles, tiles_per_split;
+  int want_db;           // 1: the slab's last column (JG-1) carries the bias gradient (column sums of dG), see below
+};
+struct WgradArgs {
+  long dG_img_stride; int dG_pix_stride;
+  WgSrc s[2];
+  int nparts;            // 1, or 2: BOTH sources in one launch (same kernel shape), their workgroups interleaved per gate block so
+                         // that the x and h workgroups of a pixel range run together and share the dG tiles in L2
+  int NTC, J;            // channel tiles per block, (tap, channel-tile) columns in all
+  int TG;                // column groups of 4*JW columns (49 taps of a 7x7 kernel: 2)
   int k, p, taps;
   int P, Wh;
-  int tiles_x, tiles_y, ntiles, tiles_per_split;
-  int want_db;           // 1: the slab's last column (JG-1) carries the bias gradient (column sums of dG), see below
+  int tiles_x, tiles_y;
 };
 
 template <int DT> struct WgTile;
@@ -74,12 +83,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   constexpr int NI_A = NA_U / 64, NI_B = NB_U_PAD / 64, NI = NI_A + NI_B;
 
   // (integer division runs on the vector ALU: readfirstlane puts the workgroup-uniform results back into scalars)
-  const int tg = __builtin_amdgcn_readfirstlane(blockIdx.y % a.TG);   // column group
-  const int bc = __builtin_amdgcn_readfirstlane(blockIdx.y / a.TG);   // (gate block, channel block)
-  const int nb = bc / a.CB, cb = bc % a.CB;
+  int by = blockIdx.y, part = 0;
+  if (a.nparts == 2) {                        // per gate block: the x source's channel blocks, then the h source's (TG == 1)
+    const int per_nb = a.s[0].CB + a.s[1].CB;
+    const int nbq = by / per_nb, r = by - nbq * per_nb;
+    part = r >= a.s[0].CB ? 1 : 0;
+    by = part ? nbq * a.s[1].CB + (r - a.s[0].CB) : nbq * a.s[0].CB + r;
+  }
+  part = __builtin_amdgcn_readfirstlane(part);
+  by = __builtin_amdgcn_readfirstlane(by);
+  // (this source's fields, read once into scalars: the tile loop must not index the argument table)
+  struct { const char* dG; const char* src; long src_img_stride; int src_pix_stride; float* partial; int CB, JG, nblk, ntiles, tiles_per_split, want_db; } S;
+  {
+    const WgSrc& T = a.s[part];
+    S.dG = T.dG; S.src = T.src; S.src_img_stride = T.src_img_stride; S.src_pix_stride = T.src_pix_stride; S.partial = T.partial;
+    S.CB = T.CB; S.JG = T.JG; S.nblk = T.nblk; S.ntiles = T.ntiles; S.tiles_per_split = T.tiles_per_split; S.want_db = T.want_db;
+  }
+  const int tg = __builtin_amdgcn_readfirstlane(by % a.TG);   // column group
+  const int bc = __builtin_amdgcn_readfirstlane(by / a.TG);   // (gate block, channel block)
+  const int nb = bc / S.CB, cb = bc % S.CB;
   const int jb = tg * 4 * JW;                 // first column of this workgroup
-  const int t_begin = blockIdx.x * a.tiles_per_split;
-  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const int t_begin = blockIdx.x * S.tiles_per_split;
+  const int t_end = min(S.ntiles, t_begin + S.tiles_per_split);
   const int i0 = (wave % NS) * NTN;           // first row tile (16 gate columns each) of this wave
   const int j0 = (wave / NS) * JW;
 
@@ -91,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 
   // bias gradient: channel block 0 / LAST column group of the source that carries it, on the last wave -- which has
   // fewer than JW real columns there (host-checked), so its accumulator column JW-1 is free: no extra registers
-  const bool do_db = __builtin_amdgcn_readfirstlane((a.want_db && cb == 0 && tg == a.TG - 1 && wave == 3 && NS == 1) ? 1 : 0);
+  const bool do_db = __builtin_amdgcn_readfirstlane((S.want_db && cb == 0 && tg == a.TG - 1 && wave == 3 && NS == 1) ? 1 : 0);
 
   // DMA pieces of a tile are dealt to the waves in CONTIGUOUS ranges sized to even out each wave's work per tile:
   // a wave with fewer real columns (25 taps over 4 waves = 7, 7, 7, 4) has idle issue slots that the staging of the
@@ -143,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       const int u = (t - NI_A) * 64 + lane;
       const int hp = u / UB_PIX, q = u - hp * UB_PIX;
       const int hy = hp / HWt, hx = hp - hy * HWt;
-      if (hp < HHt * HWt && q < b_units_pix) o = (unsigned)((hy * a.Wh + hx) * a.src_pix_stride + q * 16);
+      if (hp < HHt * HWt && q < b_units_pix) o = (unsigned)((hy * a.Wh + hx) * S.src_pix_stride + q * 16);
     }
     doff[i] = o;
   }
@@ -155,13 +180,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     ld_img = r / a.tiles_y;
     ld_ty = r - ld_img * a.tiles_y;
   }
-  const char* const ga0 = a.dG + nb * 64 * E::ES;
-  const char* const gb0 = a.src + cb * 16 * NTCT * E::ES;
+  const char* const ga0 = S.dG + nb * 64 * E::ES;
+  const char* const gb0 = S.src + cb * 16 * NTCT * E::ES;
 
   auto issue_dma = [&](char* buf) {          // stages tile (ld_img, ld_ty, ld_tx) into buf, then steps to the next tile
     const int y0 = ld_ty * PR, x0 = ld_tx * 32;
     const char* ga = ga0 + (long)ld_img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride;
-    const char* gb = gb0 + (long)ld_img * a.src_img_stride + ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.src_pix_stride;
+    const char* gb = gb0 + (long)ld_img * S.src_img_stride + ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * S.src_pix_stride;
 #pragma unroll
     for (int i = 0; i < NI_WM; ++i) {
       const int t = p_begin + i;               // wave-uniform
@@ -301,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 
   // ---- flush: partial[split][blockIdx.y][j local][n'loc 64][c 16]
-  float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * a.JG * 1024;
+  float* out = S.partial + ((size_t)blockIdx.x * S.nblk + by) * S.JG * 1024;
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) {
     const int j = j0 + jj;
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < NTN; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        out[(size_t)(a.JG - 1) * 1024 + ((i0 + i) * 16 + 4 * g + r) * 16 + i16] = acc[i][JW - 1][r];
+        out[(size_t)(S.JG - 1) * 1024 + ((i0 + i) * 16 + 4 * g + r) * 16 + i16] = acc[i][JW - 1][r];
   }
 }
 
@@ -393,6 +418,8 @@ struct WgPlan {
   WgPart part[2];
   int NB, tiles_x, tiles_y, ntiles;
   size_t off_h, total_floats;
+  bool merged;            // both sources in ONE launch (narrow layers: the launches are bound by re-reading dG, and the x and h
+                          // workgroups of a pixel range then share its tiles in L2)
 };
 
 static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_geom* g, WgPlan* pl) {
@@ -430,6 +457,23 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
     // re-derive the split count so that no split is empty
     w.splits = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
     floats[q] = (size_t)w.splits * pl->NB * w.CB * w.TG * w.JG * 1024;
+  }
+  // same kernel shape for both sources and few workgroup columns: one launch, one split count
+  const WgPart &wx = pl->part[0], &wh = pl->part[1];
+  pl->merged = wx.NTC == wh.NTC && wx.JW == wh.JW && wx.KX == wh.KX && wx.TG == 1 && wh.TG == 1 && pl->NB * (wx.CB + wh.CB) <= 8;
+  if (pl->merged) {
+    int s = nint_cdiv(2 * n_cu, pl->NB * (wx.CB + wh.CB));
+    if (s > pl->ntiles / 32) s = pl->ntiles / 32;
+    if (s < 1) s = 1;
+    s = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
+    // a multiple of 8 splits: workgroup (split, column) sits on XCD (split + splits * column) % 8, so all columns of a split
+    // -- the workgroups that read the same dG tiles -- then share one L2 (86 splits for layer 1: 534 us; 80: see DESIGN.md)
+    if (s >= 8) s -= s % 8;
+    for (int q = 0; q < 2; ++q) {
+      WgPart& w = pl->part[q];
+      w.splits = s;
+      floats[q] = (size_t)w.splits * pl->NB * w.CB * w.TG * w.JG * 1024;
+    }
   }
   pl->off_h = floats[0];
   pl->total_floats = floats[0] + floats[1];
@@ -511,31 +555,37 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
     float* base = partial + off;
     off += (pl.total_floats + 63) / 64 * 64;
     const int Gc = 4 * ly->Ch16;
+    WgradArgs a = {};
+    a.dG_pix_stride = Gc * es;
+    a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
+    a.k = ly->k; a.p = ly->k / 2;
+    a.P = g->P; a.Wh = g->Wh;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
     for (int part = 0; part < 2; ++part) {
       const WgPart& w = pl.part[part];
-      WgradArgs a = {};
-      a.dG_pix_stride = Gc * es;
-      a.dG_img_stride = (long)g->Hh * g->Wh * a.dG_pix_stride;
+      WgSrc& S = a.s[pl.merged ? part : 0];
       const int skip = part == 1 ? jb.h_skip : 0;
-      a.dG = (const char*)jb.dG + (size_t)skip * a.dG_img_stride;
+      S.dG = (const char*)jb.dG + (size_t)skip * a.dG_img_stride;
       const int Cp = part == 0 ? ly->Cxp : ly->Chp;
-      a.src_pix_stride = Cp * es;
-      a.src_img_stride = (long)g->Hh * g->Wh * a.src_pix_stride;
-      a.src = (const char*)(part == 0 ? jb.x_slab : jb.h_slab) + (size_t)skip * a.src_img_stride;
-      a.partial = base + (part == 0 ? 0 : pl.off_h);
-      a.CB = w.CB;
-      a.NTC = w.NTC; a.J = w.J; a.TG = w.TG; a.JG = w.JG;
-      a.want_db = part == 0 ? 1 : 0;           // the x part sees every image (the h part may skip the first time step)
-      a.k = ly->k; a.p = ly->k / 2; a.taps = ly->k * w.KX;
-      a.P = g->P; a.Wh = g->Wh;
-      a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
-      a.ntiles = (jb.N - skip) * pl.tiles_x * pl.tiles_y;  // empty splits flush zeros
-      a.tiles_per_split = a.ntiles > 0 ? nint_cdiv(a.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
-      const int nblk = pl.NB * a.CB * w.TG;
-      rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);
-      if (rc != NINT_OK) return rc;
+      S.src_pix_stride = Cp * es;
+      S.src_img_stride = (long)g->Hh * g->Wh * S.src_pix_stride;
+      S.src = (const char*)(part == 0 ? jb.x_slab : jb.h_slab) + (size_t)skip * S.src_img_stride;
+      S.partial = base + (part == 0 ? 0 : pl.off_h);
+      S.CB = w.CB; S.JG = w.JG;
+      S.nblk = pl.NB * w.CB * w.TG;
+      S.want_db = part == 0 ? 1 : 0;           // the x part sees every image (the h part may skip the first time step)
+      S.ntiles = (jb.N - skip) * pl.tiles_x * pl.tiles_y;  // empty splits flush zeros
+      S.tiles_per_split = S.ntiles > 0 ? nint_cdiv(S.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
+      a.NTC = w.NTC; a.J = w.J; a.TG = w.TG;
+      a.taps = ly->k * w.KX;
+      if (!pl.merged || part == 1) {           // separate launches per source, or both sources in one
+        a.nparts = pl.merged ? 2 : 1;
+        const int nblk = pl.merged ? a.s[0].nblk + a.s[1].nblk : S.nblk;
+        rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);
+        if (rc != NINT_OK) return rc;
+      }
       ReduceEntry& E = rt.e[rt.n++];
-      E.part = a.partial; E.dW = jb.dW; E.db = part == 0 ? jb.db : nullptr;
+      E.part = S.partial; E.dW = jb.dW; E.db = part == 0 ? jb.db : nullptr;
       E.Cx = ly->Cx; E.Ch = ly->Ch; E.Ch16 = ly->Ch16; E.k = ly->k; E.NB = pl.NB; E.CB = w.CB; E.NTC = w.NTC; E.J = w.J;
       E.splits = w.splits; E.is_h = part; E.xfold = ly->xfold; E.TG = w.TG; E.JG = w.JG;
       E.blk_begin = blk;
