@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("NINT_LIB", os.path.join(HERE, "libnint_hip.so"))   # 
 
 NINT_F32, NINT_BF16 = 0, 1
 NINT_MAX_LAYERS = 8
+NINT_VERSION = 106     # include/nint.h NINT_VERSION: the library this binding was written against
 NINT_LOSS_SCRATCH_FLOATS = 8194
 NINT_LOSS_STATS = 8
 
@@ -97,7 +98,7 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nint_version() != 106:
+    if lib.nint_version() != NINT_VERSION:
         raise NintError("libnint_hip.so version mismatch")
     _lib = lib
     return lib

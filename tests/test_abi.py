@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in nint.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.nint_version() == 106
+    assert lib.nint_version() == _lib.NINT_VERSION == 106
     assert lib.nint_kc(0) == 16 and lib.nint_kc(1) == 32
     assert lib.nint_error_string(-2).decode().startswith("nint:")
 
@@ -144,3 +144,10 @@ def test_library_reads_no_environment_and_owns_no_streams():
     for sym in ("getenv", "secure_getenv", "hipStreamCreate", "hipStreamCreateWithFlags", "hipStreamCreateWithPriority",
                 "hipEventCreate", "hipEventCreateWithFlags"):
         assert not re.search(rf"\b{sym}\b", und), f"libnint_hip.so imports {sym}"
+
+
+def test_graft_entry_build_passes():
+    """The driver's build check: __graft_entry__.build() compiles (nothing to do when the library is current), imports the
+    package and checks the library version against the binding's."""
+    import __graft_entry__
+    __graft_entry__.build()

@@ -81,6 +81,9 @@ def main():
         c210 = timed(concurrent(kern, (2, 1, 0)))
         print(f"{name}: layers alone {each[0]:.1f} + {each[1]:.1f} + {each[2]:.1f} us; one stream {seq:.1f} us; "
               f"three streams, wide layer first {c012:.1f} us, narrow layers first {c210:.1f} us", flush=True)
+        seq12 = timed(lambda: [kern(l, main_st) for l in (1, 2)])
+        c12, c21 = timed(concurrent(kern, (1, 2))), timed(concurrent(kern, (2, 1)))
+        print(f"{name}: the two narrow layers only: one stream {seq12:.1f} us; two streams {c12:.1f} / {c21:.1f} us", flush=True)
 
 
 if __name__ == "__main__":
