@@ -152,10 +152,11 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // (nint_cell_bwd_fused: d/dh_{u-1} never goes to memory).  Chosen per layer by the K-steps of its dgrad launch:
   // measured inside the bench step on two devices (bench.py --fuse-bwd 16+mask), fusing the 18-step top layer alone gives
   // +0.7 ... +1.0 %, the 36-step layer -0.9 %, the 200-step layer -1.7 % (its workgroups run their phases in lockstep, so
-  // the heavier epilogue adds its full HBM time instead of hiding behind the other workgroup's matrix work).  A fused layer consumes the x columns that the layer above
-  // produced for time u-1, so it runs ONE time step behind the layer above: at outer step s layer l works on time
-  // u_l = s + off_l, off_l = number of fused layers among l..L-1.  Fused layer: u = T -> pointwise backward of T-1 alone
-  // (d/dh_{T-1} comes from the head / the caller), 1 <= u <= T-1 -> X[u], u = 0 -> plain conv backward-data of time 0.
+  // the heavier epilogue adds its full HBM time instead of hiding behind the other workgroup's matrix work).
+  // A fused layer consumes the x columns that the layer above produced for time u-1, so it runs ONE time step behind the
+  // layer above: at outer step s layer l works on time u_l = s + off_l, off_l = number of fused layers among l..L-1.
+  // Fused layer: u = T -> pointwise backward of T-1 alone (d/dh_{T-1} comes from the head / the caller),
+  // 1 <= u <= T-1 -> X[u], u = 0 -> plain conv backward-data of time 0.
   bool fused[NINT_MAX_LAYERS];
   int off[NINT_MAX_LAYERS];
   for (int l = L - 1; l >= 0; --l) {
