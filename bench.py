@@ -137,7 +137,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="cfg1-20level", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fuse-bwd", type=int, default=0, help="nint_seq.fuse_bwd (BPTT schedule; 0 = the library's per-layer choice)")
+    ap.add_argument("--fuse-bwd", type=lambda v: int(v, 0), default=0,
+                    help="nint_seq.fuse_bwd (BPTT schedule; 0 = the library's per-layer choice, 0x10000|mask = explicit, see nint.h)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 

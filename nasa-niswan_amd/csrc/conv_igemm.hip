@@ -537,10 +537,20 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     //   dc <- dct*f                                                     (autograd of model.py:222-229)
     // x columns are stored, or accumulated onto what a classic layer below keeps in its dh buffer (out0_overwrite).
     // All loads of a batch of rows are issued before its first store (vmcnt retires in order and counts stores).
+    // With lo_gates set the x columns get the same treatment: they are the LAST contribution to d/dh of the layer BELOW at
+    // this launch's own time step (that layer's h columns of the next time step are already in out0), so its pointwise
+    // backward runs here too and its stand-alone launch disappears.
     typedef Pk4<DT> PK;
-    const int Gc = 4 * a.Ch16;
     constexpr int RB0 = NTW >= 4 ? 1 : 4 / NTW;                  // rows per batch: about 4 column tiles (88 registers) in flight
     constexpr int RB = RB0 >= Q ? Q : (Q % RB0 == 0 ? RB0 : 1);
+    // per column tile (wave-uniform): 0 = x columns stored / accumulated, 1 = pointwise backward of this layer (h columns),
+    // 2 = pointwise backward of the layer below (x columns), -1 = padding
+    auto tile_kind = [&](int j, int& ch0) __attribute__((always_inline)) {
+      const int n0 = (nt0 + j) * 16;
+      if (n0 >= a.C0p) { ch0 = n0 - a.C0p; return ch0 < a.Ch16 ? 1 : -1; }
+      ch0 = n0;
+      return a.lo_gates ? (ch0 < a.lo_Ch16 ? 2 : -1) : 0;
+    };
 #pragma unroll
     for (int ib = 0; ib < Q; ib += RB) {
       typename PK::T gq[RB][NTW][4], oldv[RB][NTW];
@@ -553,24 +563,33 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
         const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-          const int hch = (nt0 + j) * 16 - a.C0p;                 // first hidden channel of this column tile (tile-uniform)
+          int ch0;
+          const int kind = tile_kind(j, ch0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) gq[ii][j][q] = PK::zero();
           oldv[ii][j] = PK::zero();
           cpq[ii][j] = cnq[ii][j] = dcq[ii][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          if (hch < 0) {                                          // x columns accumulating onto a classic layer's h columns
-            if (a.out0 && !a.out0_overwrite && okp) oldv[ii][j] = PK::ld(a.out0, rowpix * a.C0p + (unsigned)(x * a.C0p + (nt0 + j) * 16 + c4));
-          } else if (hch < a.Ch16 && okp) {
-            const size_t pix = rowpix + x;
-            const size_t gb = pix * Gc + (size_t)(hch >> 4) * 64 + c4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gq[ii][j][q] = PK::ld(a.pw_gates, gb + 16 * q);
-            const size_t ci = pix * a.Chp + hch + c4;
-            if (a.pw_c_prev) cpq[ii][j] = *(const f32x4_t*)(a.pw_c_prev + ci);
-            cnq[ii][j] = *(const f32x4_t*)(a.pw_c_new + ci);
-            dcq[ii][j] = *(const f32x4_t*)(a.pw_dc + ci);
-            if (a.pw_old) oldv[ii][j] = PK::ld(a.pw_old, ci);
+          if (!okp || kind < 0) continue;
+          const size_t pix = rowpix + x;
+          if (kind != 1) {                                         // x columns: what a classic layer below keeps in its dh buffer
+            if (a.out0 && !a.out0_overwrite) oldv[ii][j] = PK::ld(a.out0, pix * a.C0p + ch0 + c4);
+          } else if (a.pw_old) {
+            oldv[ii][j] = PK::ld(a.pw_old, pix * a.Chp + ch0 + c4);
           }
+          if (kind == 0) continue;
+          const bool lo = kind == 2;
+          const int Gc = 4 * (lo ? a.lo_Ch16 : a.Ch16), Cp = lo ? a.C0p : a.Chp;
+          const char* gp = lo ? a.lo_gates : a.pw_gates;
+          const float* cpp = lo ? a.lo_c_prev : a.pw_c_prev;
+          const float* cnp = lo ? a.lo_c_new : a.pw_c_new;
+          const float* dcp_ = lo ? (a.lo_dc_zero ? nullptr : a.lo_dc) : a.pw_dc;
+          const size_t gb = pix * Gc + (size_t)(ch0 >> 4) * 64 + c4;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gq[ii][j][q] = PK::ld(gp, gb + 16 * q);
+          const size_t ci = pix * Cp + ch0 + c4;
+          if (cpp) cpq[ii][j] = *(const f32x4_t*)(cpp + ci);
+          cnq[ii][j] = *(const f32x4_t*)(cnp + ci);
+          if (dcp_) dcq[ii][j] = *(const f32x4_t*)(dcp_ + ci);
         }
       }
 #pragma unroll
@@ -582,34 +601,37 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
         const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-          const int n = (nt0 + j) * 16 + c4;
-          const int hch = (nt0 + j) * 16 - a.C0p;
-          if (hch < 0) {
-            if (a.out0 && okp) store_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + n), acc[i][j] + PK::up(oldv[ii][j]));
-          } else if (hch < a.Ch16 && okp) {
-            const f32x4_t gi = PK::up(gq[ii][j][0]), gf = PK::up(gq[ii][j][1]), gg = PK::up(gq[ii][j][2]), go = PK::up(gq[ii][j][3]);
-            const f32x4_t dhv = acc[i][j] + PK::up(oldv[ii][j]);
-            const f32x4_t cp = cpq[ii][j], cn = cnq[ii][j], dcv = dcq[ii][j];
-            f32x4_t o_i, o_f, o_g, o_o, dcp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float tc = tanhf_(cn[e]);
-              const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
-              const float d_o = dhv[e] * tc;
-              o_i[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
-              o_f[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
-              o_g[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
-              o_o[e] = d_o * go[e] * (1.f - go[e]);
-              dcp[e] = dct * gf[e];
-            }
-            char* grow = a.pw_dG + ((((size_t)img * a.Hh) + (y + a.P)) * a.Wh + (xo + a.P)) * Gc * Elem<DT>::ES;
-            const unsigned ob = (unsigned)(x * Gc + (hch >> 4) * 64 + c4);
-            store_vec4<DT>(grow, ob, o_i);
-            store_vec4<DT>(grow, ob + 16, o_f);
-            store_vec4<DT>(grow, ob + 32, o_g);
-            store_vec4<DT>(grow, ob + 48, o_o);
-            *(f32x4_t*)(a.pw_dc + (rowpix + x) * a.Chp + hch + c4) = dcp;
+          int ch0;
+          const int kind = tile_kind(j, ch0);
+          if (!okp || kind < 0) continue;
+          const f32x4_t dhv = acc[i][j] + PK::up(oldv[ii][j]);
+          if (kind == 0) {
+            if (a.out0) store_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + ch0 + c4), dhv);
+            continue;
           }
+          const bool lo = kind == 2;
+          const int Gc = 4 * (lo ? a.lo_Ch16 : a.Ch16), Cp = lo ? a.C0p : a.Chp;
+          const f32x4_t gi = PK::up(gq[ii][j][0]), gf = PK::up(gq[ii][j][1]), gg = PK::up(gq[ii][j][2]), go = PK::up(gq[ii][j][3]);
+          const f32x4_t cp = cpq[ii][j], cn = cnq[ii][j], dcv = dcq[ii][j];
+          f32x4_t o_i, o_f, o_g, o_o, dcp;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float tc = tanhf_(cn[e]);
+            const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
+            const float d_o = dhv[e] * tc;
+            o_i[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+            o_f[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+            o_g[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+            o_o[e] = d_o * go[e] * (1.f - go[e]);
+            dcp[e] = dct * gf[e];
+          }
+          char* grow = (lo ? a.lo_dG : a.pw_dG) + ((((size_t)img * a.Hh) + (y + a.P)) * a.Wh + (xo + a.P)) * Gc * Elem<DT>::ES;
+          const unsigned ob = (unsigned)(x * Gc + (ch0 >> 4) * 64 + c4);
+          store_vec4<DT>(grow, ob, o_i);
+          store_vec4<DT>(grow, ob + 16, o_f);
+          store_vec4<DT>(grow, ob + 32, o_g);
+          store_vec4<DT>(grow, ob + 48, o_o);
+          *(f32x4_t*)((lo ? a.lo_dc : a.pw_dc) + (rowpix + x) * Cp + ch0 + c4) = dcp;
         }
       }
     }
@@ -823,6 +845,11 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   if (pw) {
     a.pw_gates = (const char*)pw->gates; a.pw_c_prev = pw->c_prev; a.pw_c_new = pw->c_new; a.pw_dc = pw->dc;
     a.pw_old = (const char*)pw->old; a.pw_dG = (char*)pw->dG_out;
+    if (pw->lo_gates) {                        // the layer below's pointwise backward of this time step, on the x columns
+      if (!dx_accum || !pw->lo_c_new || !pw->lo_dc || !pw->lo_dG_out || pw->lo_Ch16 <= 0 || pw->lo_Ch16 > ly->Cxp) return NINT_E_ARG;
+      a.lo_gates = (const char*)pw->lo_gates; a.lo_c_prev = pw->lo_c_prev; a.lo_c_new = pw->lo_c_new; a.lo_dc = pw->lo_dc;
+      a.lo_dG = (char*)pw->lo_dG_out; a.lo_Ch16 = pw->lo_Ch16; a.lo_dc_zero = pw->lo_dc_zero ? 1 : 0;
+    }
     return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD_PW>(a, N, ntiles, st)
                               : launch_conv<NINT_F32, EPI_DGRAD_PW>(a, N, ntiles, st);
   }
@@ -833,6 +860,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
 extern "C" int nint_cell_bwd_fused(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG_next, void* dx,
                                    const void* gates, const float* c_prev, const float* c_new, const void* dh_above,
                                    float* dc, void* dG, void* stream) {
-  const DgradPw pw = {gates, c_prev, c_new, dc, dh_above, dG};
+  DgradPw pw = {};
+  pw.gates = gates; pw.c_prev = c_prev; pw.c_new = c_new; pw.dc = dc; pw.old = dh_above; pw.dG_out = dG;
   return nint_internal_conv_dgrad(ly, g, dtype, N, dG_next, dx, nullptr, true, &pw, stream);
 }

@@ -153,6 +153,9 @@ struct ConvArgs {
   float* pw_dc;          // d/dc, read and overwritten in place
   const char* pw_old;    // the x columns the layer above left for this step (ET compact [N][H][W][Chp]) or nullptr
   char* pw_dG;           // dG halo slab of that step
+  // ... and of the layer BELOW at this launch's own time step, on the x columns (lo_gates == nullptr: x columns stored)
+  const char* lo_gates; const float* lo_c_prev; const float* lo_c_new; float* lo_dc; char* lo_dG;
+  int lo_Ch16, lo_dc_zero;
 };
 
 // internal entry points shared between translation units (not part of the C ABI)
@@ -171,6 +174,8 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
 int nint_internal_conv_ws_lstm(ConvArgs& a, int N, void* stream);
 struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
+  // optional: the layer below's pointwise backward of THIS time step, run on the x columns (the layer's dh buffer is only read)
+  const void* lo_gates; const float* lo_c_prev; const float* lo_c_new; float* lo_dc; void* lo_dG_out; int lo_Ch16; bool lo_dc_zero;
 };
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
                              void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream);
