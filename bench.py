@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--workload", default="cfg1-20level", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-bwd", type=lambda v: int(v, 0), default=0,
-                    help="nint_seq.fuse_bwd (BPTT schedule; 0 = the library's per-layer choice, 0x10000|mask = explicit, see nint.h)")
+                    help="nint_seq.fuse_bwd (BPTT schedule; 0 = the library's per-layer choice, 0x40000000|masks = explicit, see nint.h)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 

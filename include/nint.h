@@ -96,10 +96,11 @@ typedef struct nint_seq {
                                         * (each rounded up to 256 bytes) -- the layers' slabs sit side by side */
   size_t wg_partial_bytes;
   int32_t fuse_bwd;                    /* backward schedule: 0 = per layer (fused BPTT step for the short-K layers), 1 = never
-                                        * fused, 2 = every layer fused, 0x10000 | mask = explicit: layer l runs the fused step
-                                        * iff bit l; bit 8+l: the fused layer l also runs the pointwise backward of the
-                                        * classic layer l-1 on its x columns (nint_cell_bwd_fused; same results up to the bf16
-                                        * rounding of the intermediate dh, which the fused step skips) */
+                                        * fused, 2 = every layer fused, 0x40000000 | masks = explicit: bit l: layer l runs the
+                                        * fused step; bit 8+l: the fused layer l also runs the pointwise backward of the
+                                        * classic layer l-1 on its x columns; bit 16+l: the CLASSIC layer l does that for the
+                                        * classic layer l-1 (nint_cell_bwd_fused; same results up to the bf16 rounding of the
+                                        * intermediate dh, which the fused step skips) */
 } nint_seq;
 
 /* ---- library / device ---------------------------------------------------------------- */

@@ -547,7 +547,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     // 2 = pointwise backward of the layer below (x columns), -1 = padding
     auto tile_kind = [&](int j, int& ch0) __attribute__((always_inline)) {
       const int n0 = (nt0 + j) * 16;
-      if (n0 >= a.C0p) { ch0 = n0 - a.C0p; return ch0 < a.Ch16 ? 1 : -1; }
+      if (n0 >= a.C0p) {
+        ch0 = n0 - a.C0p;
+        if (!a.pw_gates) return (a.out1 && ch0 < a.C1p) ? 3 : -1;      // 3 = h columns stored (a classic layer's dgrad)
+        return ch0 < a.Ch16 ? 1 : -1;
+      }
       ch0 = n0;
       return a.lo_gates ? (ch0 < a.lo_Ch16 ? 2 : -1) : 0;
     };
@@ -571,12 +575,13 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
           cpq[ii][j] = cnq[ii][j] = dcq[ii][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           if (!okp || kind < 0) continue;
           const size_t pix = rowpix + x;
+          if (kind == 3) continue;
           if (kind != 1) {                                         // x columns: what a classic layer below keeps in its dh buffer
             if (a.out0 && !a.out0_overwrite) oldv[ii][j] = PK::ld(a.out0, pix * a.C0p + ch0 + c4);
           } else if (a.pw_old) {
             oldv[ii][j] = PK::ld(a.pw_old, pix * a.Chp + ch0 + c4);
           }
-          if (kind == 0) continue;
+          if (kind == 0 || kind == 3) continue;
           const bool lo = kind == 2;
           const int Gc = 4 * (lo ? a.lo_Ch16 : a.Ch16), Cp = lo ? a.C0p : a.Chp;
           const char* gp = lo ? a.lo_gates : a.pw_gates;
@@ -607,6 +612,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
           const f32x4_t dhv = acc[i][j] + PK::up(oldv[ii][j]);
           if (kind == 0) {
             if (a.out0) store_vec4<DT>(a.out0 + rowpix * a.C0p * Elem<DT>::ES, (unsigned)(x * a.C0p + ch0 + c4), dhv);
+            continue;
+          }
+          if (kind == 3) {
+            store_vec4<DT>(a.out1 + rowpix * a.C1p * Elem<DT>::ES, (unsigned)(x * a.C1p + ch0 + c4), acc[i][j]);
             continue;
           }
           const bool lo = kind == 2;
@@ -808,7 +817,10 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
                              void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream) {
   if (!ly || !g || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
-  if (pw && (!pw->gates || !pw->c_new || !pw->dc || !pw->dG_out || dh_prev)) return NINT_E_ARG;
+  // fused forms: pw->gates set = this layer's pointwise backward on the h columns (dh_prev is then not stored);
+  // pw->gates NULL + pw->lo_gates = a classic dgrad (h columns stored) that runs the LOWER layer's pointwise backward
+  if (pw && pw->gates && (!pw->c_new || !pw->dc || !pw->dG_out || dh_prev)) return NINT_E_ARG;
+  if (pw && !pw->gates && !pw->lo_gates) return NINT_E_ARG;
   if (!dx_accum && !dh_prev && !pw) return NINT_OK;
   if (!aligned16(dG) || !aligned16(ly->Wd)) return NINT_E_ALIGN;
 #ifndef NINT_EXPERIMENT
@@ -838,9 +850,9 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.tile_rows = ly->tile_rows & 0xff;
 #endif
   // only the n-tiles whose destination exists are computed (fused: the Ch16 real hidden columns, not their padding)
-  const int nt_x = ly->Cxp / 16, nt_h = pw ? ly->Ch16 / 16 : ly->Chp / 16;
+  const int nt_x = ly->Cxp / 16, nt_h = (pw && pw->gates) ? ly->Ch16 / 16 : ly->Chp / 16;
   a.nt_begin = dx_accum ? 0 : nt_x;
-  const int ntiles = (dx_accum ? nt_x : 0) + ((dh_prev || pw) ? nt_h : 0);
+  const int ntiles = (dx_accum ? nt_x : 0) + ((dh_prev || (pw && pw->gates)) ? nt_h : 0);
   hipStream_t st = (hipStream_t)stream;
   if (pw) {
     a.pw_gates = (const char*)pw->gates; a.pw_c_prev = pw->c_prev; a.pw_c_new = pw->c_new; a.pw_dc = pw->dc;
@@ -850,6 +862,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
       a.lo_gates = (const char*)pw->lo_gates; a.lo_c_prev = pw->lo_c_prev; a.lo_c_new = pw->lo_c_new; a.lo_dc = pw->lo_dc;
       a.lo_dG = (char*)pw->lo_dG_out; a.lo_Ch16 = pw->lo_Ch16; a.lo_dc_zero = pw->lo_dc_zero ? 1 : 0;
     }
+    if (pw->tile_rows) a.tile_rows = pw->tile_rows;
     return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD_PW>(a, N, ntiles, st)
                               : launch_conv<NINT_F32, EPI_DGRAD_PW>(a, N, ntiles, st);
   }

@@ -176,6 +176,7 @@ struct DgradPw {         // fused pointwise backward of the previous time step (
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
   // optional: the layer below's pointwise backward of THIS time step, run on the x columns (the layer's dh buffer is only read)
   const void* lo_gates; const float* lo_c_prev; const float* lo_c_new; float* lo_dc; void* lo_dG_out; int lo_Ch16; bool lo_dc_zero;
+  int tile_rows;          // 0 = the layer's choice, 4 / 8 = this launch's tile height
 };
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
                              void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream);

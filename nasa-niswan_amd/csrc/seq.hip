@@ -151,12 +151,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     if (!s->gates[l] || !s->dG[l] || !s->dh[l] || !s->dc[l] || !s->dW[l] || !s->db[l]) return NINT_E_ARG;
   if (s->need_dx && !s->dx) return NINT_E_ARG;
   if (!s->wg_partial) return NINT_E_ARG;
-  if (s->fuse_bwd < 0 || (s->fuse_bwd > 2 && !(s->fuse_bwd & 0x10000)) || s->fuse_bwd >= 0x20000) return NINT_E_ARG;
+  if (s->fuse_bwd < 0 || (s->fuse_bwd > 2 && !(s->fuse_bwd & 0x40000000))) return NINT_E_ARG;
 
   // BPTT.  A layer runs either the CLASSIC step (pointwise backward of time u, then conv backward-data of time u) or the
   // FUSED step X[u] = conv backward-data of time u with the pointwise backward of time u-1 in its epilogue
   // (nint_cell_bwd_fused: d/dh_{u-1} never goes to memory).  Chosen per layer by the K-steps of its dgrad launch:
-  // measured inside the bench step on two devices (bench.py --fuse-bwd 0x10000|mask), fusing the 18-step top layer alone gives
+  // measured inside the bench step on two devices (bench.py --fuse-bwd 0x40000000|masks), fusing the 18-step top layer alone gives
   // +0.7 ... +1.0 %, the 36-step layer -0.9 %, the 200-step layer -1.7 % (its workgroups run their phases in lockstep, so
   // the heavier epilogue adds its full HBM time instead of hiding behind the other workgroup's matrix work).
   // A fused layer consumes the x columns that the layer above produced for time u-1, so it runs ONE time step behind the
@@ -165,9 +165,9 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // 1 <= u <= T-1 -> X[u], u = 0 -> plain conv backward-data of time 0.
   // A fused layer above a classic one can ALSO run that layer's pointwise backward, on its x columns (they are the last
   // contribution to the lower layer's d/dh of the same time step): lo[l] -- the lower layer then only launches its dgrad.
-  bool fused[NINT_MAX_LAYERS], lo[NINT_MAX_LAYERS];
+  bool fused[NINT_MAX_LAYERS], lo[NINT_MAX_LAYERS], loc[NINT_MAX_LAYERS];
   int off[NINT_MAX_LAYERS], pw_done[NINT_MAX_LAYERS];
-  const bool explicit_mask = (s->fuse_bwd & 0x10000) != 0;
+  const bool explicit_mask = (s->fuse_bwd & 0x40000000) != 0;
   for (int l = L - 1; l >= 0; --l) {
     const nint_layer* ly = &s->layer[l];
     const int ksteps = (4 * ly->Ch16 / (s->dtype == NINT_BF16 ? 32 : 16)) * ly->k * ly->k;   // K-steps of the layer's dgrad launch
@@ -175,8 +175,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     off[l] = (l == L - 1 ? 0 : off[l + 1]) + (fused[l] ? 1 : 0);
     pw_done[l] = -1;
   }
-  for (int l = 0; l < L; ++l)
+  for (int l = 0; l < L; ++l) {
     lo[l] = fused[l] && l > 0 && !fused[l - 1] && (explicit_mask ? ((s->fuse_bwd >> (8 + l)) & 1) != 0 : NINT_AUTO_LO);
+    // ... and a CLASSIC layer can do the same for the classic layer below it (its dgrad then runs the fused kernel with the
+    // h columns stored; 4-row tiles, whose many small workgroups overlap the added HBM traffic)
+    loc[l] = !fused[l] && l > 0 && !fused[l - 1] && explicit_mask && ((s->fuse_bwd >> (16 + l)) & 1) != 0;
+  }
   const int T = s->T;
   for (int so = T - 1; so >= -off[0]; --so) {
     for (int l = L - 1; l >= 0; --l) {
@@ -206,7 +210,19 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           rc = pointwise(u);
           if (rc != NINT_OK) return rc;
         }
-        rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, nullptr, stream);
+        DgradPw pw = {};
+        if (loc[l]) {
+          const nint_layer* lb = &s->layer[l - 1];
+          const size_t cs_b = (size_t)B * comp_px * lb->Chp, Gc_b = 4 * (size_t)lb->Ch16;
+          pw.lo_gates = (const char*)s->gates[l - 1] + (size_t)u * B * comp_px * Gc_b * es;
+          pw.lo_c_prev = s->c[l - 1] + (size_t)u * cs_b; pw.lo_c_new = s->c[l - 1] + (size_t)(u + 1) * cs_b;
+          pw.lo_dc = s->dc[l - 1]; pw.lo_dG_out = (char*)s->dG[l - 1] + (size_t)u * B * halo_px * Gc_b * es;
+          pw.lo_Ch16 = lb->Ch16;
+          pw.lo_dc_zero = u == T - 1 && ((s->zero_dstate >> (2 * (l - 1))) & 1);
+          pw.tile_rows = 4;
+          pw_done[l - 1] = u;
+        }
+        rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, loc[l] ? &pw : nullptr, stream);
       } else if (u == T) {
         rc = pointwise(T - 1);
       } else if (u >= 1) {

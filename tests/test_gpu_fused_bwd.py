@@ -89,12 +89,13 @@ def test_fused_step_equals_dgrad_then_pointwise(pkg, dtype, H, W, B):
         assert float(d4[:, P + H:].abs().max()) == 0 and float(d4[:, :, P + W:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("mode", [1, 2, 0x10404, 0x10202, 0x10205])
+@pytest.mark.parametrize("mode", [1, 2, 0x40000404, 0x40000202, 0x40000005, 0x40020404, 0x40060000])
 def test_backward_schedules_keep_parity(pkg, mode):
     """nint_seq.fuse_bwd: 1 = every layer runs the classic pair, 2 = every layer runs the fused step, one time step behind
-    the layer above (the default, 0, mixes them per layer and is what the rest of the suite runs); 0x10000 | masks =
-    explicit: 0x10404 layer 2 fused and running layer 1's pointwise backward on its x columns, 0x10202 the same one layer
-    down, 0x10205 layers 0 and 2 fused, layer 1 classic.  Every gradient, the input gradient included, against the oracle on
+    the layer above (the default, 0, mixes them per layer and is what the rest of the suite runs); 0x40000000 | masks =
+    explicit: ..404 layer 2 fused and running layer 1's pointwise backward on its x columns, ..202 the same one layer
+    down, ..005 layers 0 and 2 fused, layer 1 classic, 0x4002.... / 0x4006....: classic layers 1 (and 2) run the pointwise
+    backward of the classic layer below on their x columns.  Every gradient, the input gradient included, against the oracle on
     ragged / multi-layer / reference-size shapes, T = 1 .. 3."""
     from nasa_niswan_amd import engine
     from test_gpu_shapes import CASES, check, run_case
