@@ -362,7 +362,7 @@ struct ReduceEntry {
 struct ReduceTable { ReduceEntry e[2 * NINT_MAX_LAYERS]; int n; };
 
 __global__ void wgrad_reduce_kernel(ReduceTable t) {
-  __shared__ float red[1024];
+  __shared__ f32x4_t red[1024];
   int ei = 0;
   for (int q = 1; q < t.n; ++q) ei = blockIdx.x >= t.e[q].blk_begin ? q : ei;     // entries are in launch order
   const ReduceEntry& E = t.e[ei];
@@ -373,17 +373,18 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   const int taps = k * k, Ctot = Cx + Ch;
   const size_t slab = (size_t)E.NB * CB * TG * JG * 1024;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, G = E.waves;   // waves >= G idle through the barrier
-  const size_t i = (size_t)(blockIdx.x - E.blk_begin) * 64 + lane;       // slab is a multiple of 1024: no tail
-  float s = 0.f;
+  // a workgroup owns 256 consecutive slab elements, 4 per lane (16-byte loads: 1 KiB per wave and split)
+  const size_t i = ((size_t)(blockIdx.x - E.blk_begin) * 64 + lane) * 4;  // slab is a multiple of 1024: no tail
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
   if (grp < G) {
 #pragma unroll 4
-    for (int sp = grp; sp < splits; sp += G) s += part[i + (size_t)sp * slab];
+    for (int sp = grp; sp < splits; sp += G) s += *(const f32x4_t*)(part + i + (size_t)sp * slab);
   }
   red[threadIdx.x] = s;
   __syncthreads();
   if (grp != 0) return;
   for (int q = 1; q < G; ++q) s += red[q * 64 + lane];
-  const int c16 = i & 15, nloc = (i >> 4) & 63;
+  const int c16 = i & 15, nloc = (i >> 4) & 63;       // c16 is a multiple of 4: the lane's elements are channels c16 .. c16+3
   size_t r = i >> 10;
   const int jl = r % JG; r /= JG;
   const int tgi = r % TG; r /= TG;
@@ -392,24 +393,28 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   const int np = nb * 64 + nloc;                      // gate column n' = (cblock*4+gate)*16+col
   const int ch = (np >> 6) * 16 + (np & 15), gate = (np >> 4) & 3;
   const int JR = JG - (E.db ? 1 : 0);                 // real columns per group
-  if (jl >= JR) {                                     // the bias-gradient column
-    if (cb == 0 && tgi == TG - 1 && c16 == 0 && ch < Ch) E.db[gate * Ch + ch] = s;
+  if (jl >= JR) {                                     // the bias-gradient column (all 16 "channels" hold the same sum)
+    if (cb == 0 && tgi == TG - 1 && c16 == 0 && ch < Ch) E.db[gate * Ch + ch] = s[0];
     return;
   }
   const int j = tgi * JR + jl;
-  if (j >= J) return;                                 // unused slots of the last column group
-  int tap = j / NTC;
-  const int ct = j - tap * NTC;
-  int cc = (cb * NTC + ct) * 16 + c16;                // channel inside this source
-  int Csrc = is_h ? Ch : Cx;
-  if (!is_h && E.xfold) {                             // folded x source: column (ky, kx*Cx + c) -> W[.][c][ky][kx]
-    if (cc >= k * Cx) return;
-    tap = tap * k + cc / Cx;
-    cc = cc % Cx;
+  if (j >= J || ch >= Ch) return;                     // unused slots of the last column group / padding rows
+  const int tap0 = j / NTC;
+  const int ct = j - tap0 * NTC;
+  const int Csrc = is_h ? Ch : Cx;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int cc = (cb * NTC + ct) * 16 + c16 + e;          // channel inside this source
+    int tap = tap0;
+    if (!is_h && E.xfold) {                           // folded x source: column (ky, kx*Cx + c) -> W[.][c][ky][kx]
+      if (cc >= k * Cx) continue;
+      tap = tap0 * k + cc / Cx;
+      cc = cc % Cx;
+    }
+    if (cc >= Csrc) continue;                         // padding columns
+    const int ic = is_h ? Cx + cc : cc;
+    dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s[e];
   }
-  if (cc >= Csrc || ch >= Ch) return;                 // padding rows / columns
-  const int ic = is_h ? Cx + cc : cc;
-  dW[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + tap] = s;
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -589,7 +594,7 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       E.Cx = ly->Cx; E.Ch = ly->Ch; E.Ch16 = ly->Ch16; E.k = ly->k; E.NB = pl.NB; E.CB = w.CB; E.NTC = w.NTC; E.J = w.J;
       E.splits = w.splits; E.is_h = part; E.xfold = ly->xfold; E.TG = w.TG; E.JG = w.JG;
       E.blk_begin = blk;
-      blk += (unsigned)((size_t)pl.NB * w.CB * w.TG * w.JG * 1024 / 64);
+      blk += (unsigned)((size_t)pl.NB * w.CB * w.TG * w.JG * 1024 / 256);
       E.waves = w.splits >= 64 ? 16 : 4;         // few large slabs: 4 waves share the splits; many small slabs: 16 waves
       if (E.waves * 64 > red_threads) red_threads = E.waves * 64;
     }
