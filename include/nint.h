@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 106
+#define NINT_VERSION 107
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
 
@@ -64,6 +64,10 @@ typedef struct nint_layer {
                            * kx*Cx + c holds x[.., x + kx - k/2][c] (0 outside the image), Cxp = roundup(k*Cx, KC), and
                            * the x part of K is k vertical taps x k*Cx channels instead of k*k taps x Cx channels padded
                            * to KC each (reference layer 0: Conv2d(5+64 -> 256, k=5), model.py:207-211: 5 x-steps, not 25) */
+  int32_t wide;           /* gate / dgrad kernel family: 0 = chosen per launch shape; 1 = always the 4-wave kernels whose waves
+                           * stream their own weight fragments from L2 (csrc/conv_igemm.hip); 2 = the 8-wave kernel that stages
+                           * each K-step's weight tile ONCE per workgroup in LDS (csrc/conv_wide.hip) wherever it is
+                           * instantiated (bf16, 256 gate columns).  Same arithmetic, same summation order per output. */
   const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */
   const void* Wd;         /* dgrad weights (transposed + flipped), ET */
   const float* bias_p;    /* bias permuted to gate-stash column order [4*Ch16] */
@@ -101,7 +105,17 @@ typedef struct nint_seq {
                                         * classic layer l-1 on its x columns; bit 16+l: the CLASSIC layer l does that for the
                                         * classic layer l-1 (nint_cell_bwd_fused; same results up to the bf16 rounding of the
                                         * intermediate dh, which the fused step skips) */
+  int32_t probe_mask;                  /* in-step timing probes (diagnostic; 0 = none): bit k brackets every launch of kind k
+                                        * (NINT_PROBE_*) of nint_seq_fwd / nint_seq_bwd with two one-thread stamp launches */
+  unsigned long long* probe;           /* device buffer of probe_slots {tag, s_memrealtime (100 MHz)} pairs, or NULL.  nint_seq_fwd
+                                        * fills slots from 0, nint_seq_bwd from probe_slots / 2; each starts with two back-to-back
+                                        * calibration stamps (kind 0).  tag = kind | layer << 8 | t << 16 | end << 31 */
+  int32_t probe_slots;
 } nint_seq;
+
+/* launch kinds for nint_seq.probe_mask / the probe tags */
+enum { NINT_PROBE_CAL = 0, NINT_PROBE_GATE = 1, NINT_PROBE_POINTWISE = 2, NINT_PROBE_DGRAD = 3, NINT_PROBE_FUSED = 4,
+       NINT_PROBE_WGRAD = 5, NINT_PROBE_FOLD = 6 };
 
 /* ---- library / device ---------------------------------------------------------------- */
 int nint_version(void);

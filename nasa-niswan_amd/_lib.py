@@ -8,11 +8,12 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NINT_LIB", os.path.join(HERE, "libnint_hip.so"))   # NINT_LIB: experiment builds
+LIB_PATH = os.path.join(HERE, "libnint_hip.so")     # the one product library; nothing in the environment can swap it
 
 NINT_F32, NINT_BF16 = 0, 1
+NINT_OK, NINT_E_ARG, NINT_E_SHAPE, NINT_E_LDS, NINT_E_ALIGN = 0, -1, -2, -3, -4
 NINT_MAX_LAYERS = 8
-NINT_VERSION = 106     # include/nint.h NINT_VERSION: the library this binding was written against
+NINT_VERSION = 107     # include/nint.h NINT_VERSION: the library this binding was written against
 NINT_LOSS_SCRATCH_FLOATS = 8194
 NINT_LOSS_STATS = 8
 
@@ -25,7 +26,7 @@ class NintGeom(C.Structure):
 
 class NintLayer(C.Structure):
     _fields_ = [("Cx", C.c_int32), ("Cxp", C.c_int32), ("Ch", C.c_int32), ("Ch16", C.c_int32), ("Chp", C.c_int32),
-                ("k", C.c_int32), ("tile_rows", C.c_int32), ("xfold", C.c_int32),
+                ("k", C.c_int32), ("tile_rows", C.c_int32), ("xfold", C.c_int32), ("wide", C.c_int32),
                 ("Wf", vp), ("Wd", vp), ("bias_p", vp)]
 
 
@@ -36,7 +37,8 @@ class NintSeq(C.Structure):
                 ("xs", vp), ("h", vp * NINT_MAX_LAYERS), ("c", vp * NINT_MAX_LAYERS),
                 ("gates", vp * NINT_MAX_LAYERS), ("dG", vp * NINT_MAX_LAYERS), ("dh", vp * NINT_MAX_LAYERS),
                 ("dc", vp * NINT_MAX_LAYERS), ("dx", vp), ("dW", vp * NINT_MAX_LAYERS), ("db", vp * NINT_MAX_LAYERS),
-                ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t), ("fuse_bwd", C.c_int32)]
+                ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t), ("fuse_bwd", C.c_int32),
+                ("probe_mask", C.c_int32), ("probe", vp), ("probe_slots", C.c_int32)]
 
 
 # every symbol include/nint.h declares: name -> (restype, argtypes)
@@ -85,7 +87,9 @@ class NintError(RuntimeError):
 
 
 def load(path: str = LIB_PATH):
-    """Load the HIP library (after torch, so that both share one HIP runtime) and bind signatures."""
+    """Load the HIP library (after torch, so that both share one HIP runtime) and bind signatures.
+    ``path`` is the only way to pick another build (diagnostic tools load a -DNINT_STAMP build this way, before
+    anything else touches the package); the first successful call wins for the life of the process."""
     global _lib
     if _lib is not None:
         return _lib

@@ -112,13 +112,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-#ifdef NINT_EXPERIMENT
-  if (MT >= 8 && (a.dbg >> 8) && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1)) {
-    // stagger experiment: the second workgroup of each CU starts (dbg >> 8) microseconds late
-    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + 100ull * (a.dbg >> 8);
-    while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
   NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wk = wave / WN;
@@ -188,16 +181,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   for (int i = 0; i < MT; ++i) rowoff[i] = (rdy((i + wk * Q) % MT) * HWt + rdx((i + wk * Q) % MT)) * 16;
   const char* Bwave = a.Bp + (size_t)nt0 * 1024;   // wave-uniform (scalar) base; the lane part is a 32-bit offset
   const unsigned blane = lane * 16;
-#ifdef NINT_EXPERIMENT
-  // ablations (experiment build only, results are wrong): 0x10 weight stream re-reads one K-step (L1 hits),
-  // 0x20 no epilogue stores, 0x40 no halo fill
-  const size_t bstep = (a.dbg & 0x10) ? 0 : (size_t)a.NTt * 1024;
-  const bool abl_nostore = a.dbg & 0x20;
-  const bool abl_nofill = (a.dbg & 0x40) || ((a.dbg & 0x80) && (int)blockIdx.x >= 256 * (MT >= 8 ? 2 : 4));   // 0x80: second-round workgroups only
-#else
   const size_t bstep = (size_t)a.NTt * 1024;   // bytes between consecutive K-steps in Bp
-  constexpr bool abl_nostore = false, abl_nofill = false;
-#endif
 
   // c_{t-1} of the rows this wave finishes in the epilogue (rows (i + wk*Q) % MT, see the K-slice exchange below).
   // 4-row tiles (the narrow layers, whose time is all memory latency) fetch it HERE, ahead of the halo fill: the loads
@@ -252,7 +236,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     const int c_cnt = min(a.cpf, nchunks - c_begin);
     if (c_begin > 0) __syncthreads();          // every wave is done reading the previous image
     // ---- stage the halo tile for chunks [c_begin, c_begin+c_cnt): global -> LDS ----
-    const int a_units = abl_nofill ? 0 : c_cnt * 4 * NHPp;
+    const int a_units = c_cnt * 4 * NHPp;
     // LDS-DMA fill: one global_load_lds_dwordx4 per wave moves 64 consecutive 16-byte units of the image
     // (wave-uniform LDS base + lane*16; the SOURCE address is per lane), no VGPR round trip, so the whole
     // image is in flight at once instead of FB loads per thread.  Units of the pad pixels re-read pixel 0
@@ -483,7 +467,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
       for (int i = 0; i < Q; ++i) {
         const int rt = (i + wk * Q) % MT;        // row tile of the workgroup
         const int y = y0 + rdy(rt), xo = rdx(rt);
-        const bool ok = y < a.H && x + xo < a.W && !abl_nostore; // (the lane exchange below needs every lane: no divergent block)
+        const bool ok = y < a.H && x + xo < a.W;   // (the lane exchange below needs every lane: no divergent block)
         const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;   // (a merged tile's second column: 16 pixels on)
         const f32x4_t cp = cpv[i][cb];
         f32x4_t gi, gf, gg, go, cn, hn;
@@ -654,7 +638,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     for (int i = 0; i < Q; ++i) {
       const int rt = (i + wk * Q) % MT;
       const int y = y0 + rdy(rt), xo = rdx(rt);
-      if (y < a.H && x + xo < a.W && !abl_nostore) {
+      if (y < a.H && x + xo < a.W) {
         const size_t rowpix = ((size_t)img * a.H + y) * a.W + xo;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -742,11 +726,6 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
     if (cbs % 2 == 0) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st);
     return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st);
   } else {
-#ifdef NINT_EXPERIMENT
-    if ((a.dbg & 15) == 1 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 8>(a, N, ntiles / 4, st);
-    if ((a.dbg & 15) == 2 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 2, 2, 2, 4>(a, N, ntiles / 4, st);
-    if ((a.dbg & 15) == 3 && ntiles % 4 == 0) return launch_cfg<DT, EPI, 4, 1, 1, 8>(a, N, ntiles / 4, st);
-#endif
     // (WN, NTW) with WN*NTW dividing the tile count, widest first; leftover waves split K
     if (ntiles % 16 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, ntiles / 16, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, ntiles / 16, st);
     if (ntiles % 12 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 3, 4>(a, N, ntiles / 12, st) : launch_cfg<DT, EPI, 4, 1, 3, 8>(a, N, ntiles / 12, st);
@@ -767,9 +746,7 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   if (!ly || !g || !x_slab || !h_out || !c_out || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!(ly->k & 1) || ly->k / 2 > g->P) return NINT_E_ARG;
-#ifndef NINT_EXPERIMENT
   if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
-#endif
   if (!aligned16(x_slab) || !aligned16(h_prev) || !aligned16(ly->Wf) || !aligned16(h_out)) return NINT_E_ALIGN;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   if (ly->Cxp % kc || ly->Chp % kc || ly->Ch16 % 16 || ly->Chp < ly->Ch16) return NINT_E_ARG;
@@ -793,17 +770,7 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = (char*)h_out; a.gates_out = (char*)gates_out;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
   a.tile_rows = ly->tile_rows;
-#ifdef NINT_EXPERIMENT
-  a.dbg = ly->tile_rows >> 8;                 // experiment build: selector in the upper bits
-  a.tile_rows = ly->tile_rows & 0xff;
-#endif
   hipStream_t st = (hipStream_t)stream;
-#ifdef NINT_EXPERIMENT
-  if (dtype == NINT_BF16 && (a.dbg & 0x1000)) {   // experiment build: weight-stationary persistent kernel for the narrow layers (conv_ws.hip)
-    const int rc = nint_internal_conv_ws_lstm(a, N, stream);
-    if (rc != NINT_E_SHAPE) return rc;
-  }
-#endif
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st);
 }
@@ -823,9 +790,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   if (pw && !pw->gates && !pw->lo_gates) return NINT_E_ARG;
   if (!dx_accum && !dh_prev && !pw) return NINT_OK;
   if (!aligned16(dG) || !aligned16(ly->Wd)) return NINT_E_ALIGN;
-#ifndef NINT_EXPERIMENT
   if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
-#endif
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   const int Gc = 4 * ly->Ch16;
   ConvArgs a = {};
@@ -845,10 +810,6 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
   a.tile_rows = ly->tile_rows;
-#ifdef NINT_EXPERIMENT
-  a.dbg = ly->tile_rows >> 8;                 // experiment build: selector in the upper bits
-  a.tile_rows = ly->tile_rows & 0xff;
-#endif
   // only the n-tiles whose destination exists are computed (fused: the Ch16 real hidden columns, not their padding)
   const int nt_x = ly->Cxp / 16, nt_h = (pw && pw->gates) ? ly->Ch16 / 16 : ly->Chp / 16;
   a.nt_begin = dx_accum ? 0 : nt_x;

@@ -127,9 +127,6 @@ struct ConvArgs {
   int nhp_pad2;                         // halo-tile pixels of a merged tile (MT/2 rows x 32 pixels), rounded up to 16
   unsigned magic_nhpp2, magic_hwt2;
   int tile_rows;         // 0 = per launch shape, 4 / 8 = forced tile height
-#ifdef NINT_EXPERIMENT
-  int dbg;               // experiment build only: tile-configuration selector (upper bits of nint_layer.tile_rows)
-#endif
   int cpf;               // channel chunks per LDS A fill
   int a_bytes;           // bytes reserved for the A image
   int nhp_pad;           // halo-tile pixels rounded up to 16 (one g-plane of the A image)
@@ -158,6 +155,14 @@ struct ConvArgs {
   int lo_Ch16, lo_dc_zero;
 };
 
+// In-step timing probe (nint_seq.probe): a one-thread launch that writes {tag, s_memrealtime} into the caller's buffer.
+// Bracketing a launch with two of them costs two ordinary kernel boundaries (no event / barrier packets, which measured
+// +8-10 us per bracketed launch); the back-to-back calibration pair at the start of each pass prices those boundaries.
+struct Probe {
+  unsigned long long* buf; int cap; int n; unsigned mask; hipStream_t st;
+  void stamp(unsigned kind, int layer, int t, int end);                    // no-op unless bit `kind` of mask is set (kind 0: always)
+};
+
 // internal entry points shared between translation units (not part of the C ABI)
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
@@ -169,9 +174,7 @@ struct WgJob {           // one layer's weight / bias gradient
   int h_skip;                                // leading images whose h source is identically zero
 };
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
-                                   size_t partial_bytes, int n_cu, void* stream);
-// weight-stationary persistent gate kernel for the narrow layers (conv_ws.hip); NINT_E_SHAPE = not served, take the streaming kernel
-int nint_internal_conv_ws_lstm(ConvArgs& a, int N, void* stream);
+                                   size_t partial_bytes, int n_cu, void* stream, Probe* probe = nullptr);
 struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
   // optional: the layer below's pointwise backward of THIS time step, run on the x columns (the layer's dh buffer is only read)

@@ -18,17 +18,19 @@ static inline dim3 grid1d(size_t n, int block = 256) {
 // strided by H*W floats per channel, served from L2 after the first touch of each line.
 template <int DT>
 __global__ void pack_btchw_kernel(const float* __restrict__ src, void* __restrict__ dst, int B, int T, int C,
-                                  int Cp, int H, int W, int P, int Hh, int Wh) {
+                                  int Cp, int H, int W, int P, int Hh, int Wh, int kf) {
   const size_t total = (size_t)B * T * H * W * Cp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % Cp;
+    const int co = i % Cp;
     size_t r = i / Cp;
     const int x = r % W; r /= W;
     const int y = r % H; r /= H;
     const int b = r % B;
     const int t = r / B;
-    const float v = c < C ? src[((((size_t)b * T + t) * C + c) * H + y) * W + x] : 0.f;
-    const size_t o = ((((size_t)t * B + b) * Hh + (y + P)) * Wh + (x + P)) * Cp + c;
+    // kf > 1: horizontally folded layout, slab channel kx*C + c of pixel x = channel c of pixel x + kx - kf/2 (0 outside)
+    const int kx = co / C, c = co - kx * C, xi = x + kx - (kf >> 1);
+    const float v = (kx < kf && xi >= 0 && xi < W) ? src[((((size_t)b * T + t) * C + c) * H + y) * W + xi] : 0.f;
+    const size_t o = ((((size_t)t * B + b) * Hh + (y + P)) * Wh + (x + P)) * Cp + co;
     store_elem<DT>(dst, o, v);
   }
 }
@@ -191,23 +193,25 @@ static int pack_btchw_impl(const float* src, void* dst, int B, int T, int C, int
   hipStream_t st = (hipStream_t)stream;
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
   const size_t tile_bytes = (size_t)C * (g->W + 1) * sizeof(float);
-  if (tile_bytes <= 64 * 1024 && Cp % (dtype == NINT_BF16 ? 8 : 4) == 0) {
+  if (tile_bytes <= 160 * 1024 && Cp % (dtype == NINT_BF16 ? 8 : 4) == 0) {
     const dim3 grid((unsigned)((size_t)B * T * g->H));
     // widest row vector the alignment of every channel row allows (rows start at multiples of W floats)
     const int vw = ((((uintptr_t)src) & 15) == 0 && g->W % 4 == 0) ? 4 : (((((uintptr_t)src) & 7) == 0 && g->W % 2 == 0) ? 2 : 1);
-#define NINT_PACK(DT_, VW_) hipLaunchKernelGGL((pack_btchw_rows_kernel<DT_, VW_>), grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, \
-                                               g->H, g->W, g->P, g->Hh, g->Wh, kf)
-    if (dtype == NINT_BF16) { if (vw == 4) NINT_PACK(NINT_BF16, 4); else if (vw == 2) NINT_PACK(NINT_BF16, 2); else NINT_PACK(NINT_BF16, 1); }
-    else { if (vw == 4) NINT_PACK(NINT_F32, 4); else if (vw == 2) NINT_PACK(NINT_F32, 2); else NINT_PACK(NINT_F32, 1); }
+    // (row tiles above 64 KiB -- 65+ channels on a 1-degree grid -- need the opt-in, as the slab preproc kernel does)
+#define NINT_PACK(DT_, VW_) { auto kern = pack_btchw_rows_kernel<DT_, VW_>;                                                                     \
+    if (tile_bytes > 64 * 1024) NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes)); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh, kf); }
+    if (dtype == NINT_BF16) { if (vw == 4) NINT_PACK(NINT_BF16, 4) else if (vw == 2) NINT_PACK(NINT_BF16, 2) else NINT_PACK(NINT_BF16, 1) }
+    else { if (vw == 4) NINT_PACK(NINT_F32, 4) else if (vw == 2) NINT_PACK(NINT_F32, 2) else NINT_PACK(NINT_F32, 1) }
 #undef NINT_PACK
     NINT_LAUNCH_CHECK();
     return NINT_OK;
   }
-  if (kf > 1) return NINT_E_LDS;               // (the folded layout only exists for thin inputs: the row tile always fits)
+  // rows that do not fit the LDS tile (or an odd channel padding): one thread per slab element, plain or folded
   if (dtype == NINT_BF16)
-    hipLaunchKernelGGL(pack_btchw_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+    hipLaunchKernelGGL(pack_btchw_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh, kf);
   else
-    hipLaunchKernelGGL(pack_btchw_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh);
+    hipLaunchKernelGGL(pack_btchw_kernel<NINT_F32>, grid1d(total), dim3(256), 0, st, src, dst, B, T, C, Cp, g->H, g->W, g->P, g->Hh, g->Wh, kf);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }

@@ -95,6 +95,27 @@ extern "C" int nint_selftest(float* out, void* stream) {
 // MFMA-bound kernels evict each other's LDS / register budget), so they are not shipped.
 static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
 
+__global__ void probe_stamp_kernel(unsigned long long* slot, unsigned long long tag) {
+  if (threadIdx.x == 0) { slot[0] = tag; slot[1] = __builtin_amdgcn_s_memrealtime(); }
+}
+void Probe::stamp(unsigned kind, int layer, int t, int end) {
+  if (!buf || n >= cap || (kind != NINT_PROBE_CAL && !((mask >> kind) & 1))) return;
+  const unsigned long long tag = kind | ((unsigned long long)layer << 8) | ((unsigned long long)t << 16) | ((unsigned long long)end << 31) | (1ull << 63);
+  hipLaunchKernelGGL(probe_stamp_kernel, dim3(1), dim3(64), 0, st, buf + 2 * (size_t)n, tag);
+  ++n;
+}
+static Probe make_probe(const nint_seq* s, bool bwd, void* stream) {
+  Probe p = {};
+  if (s->probe && s->probe_mask && s->probe_slots >= 8) {
+    const int half = s->probe_slots / 2;
+    p.buf = s->probe + (bwd ? 2 * (size_t)half : 0);
+    p.cap = half; p.mask = (unsigned)s->probe_mask; p.st = (hipStream_t)stream;
+    p.stamp(NINT_PROBE_CAL, 0, 0, 0);          // two back-to-back stamps: the price of the brackets themselves
+    p.stamp(NINT_PROBE_CAL, 0, 0, 1);
+  }
+  return p;
+}
+
 static int seq_check(const nint_seq* s) {
   if (!s || s->L < 1 || s->L > NINT_MAX_LAYERS || s->B < 1 || s->T < 1) return NINT_E_ARG;
   if (s->dtype != NINT_F32 && s->dtype != NINT_BF16) return NINT_E_ARG;
@@ -113,6 +134,7 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   const size_t es = esize(s->dtype);
   const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
   const int B = s->B, L = s->L;
+  Probe probe = make_probe(s, false, stream);
   for (int t = 0; t < s->T; ++t) {                               // model.py:265
     for (int l = 0; l < L; ++l) {                                // model.py:267
       const nint_layer* ly = &s->layer[l];
@@ -127,8 +149,10 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
       char* h_out = (char*)s->h[l] + (size_t)(t + 1) * hs;
       float* c_out = s->c[l] + (size_t)(t + 1) * cs;
       char* gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
+      probe.stamp(NINT_PROBE_GATE, l, t, 0);
       rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
       if (rc != NINT_OK) return rc;
+      probe.stamp(NINT_PROBE_GATE, l, t, 1);
     }
   }
   return NINT_OK;
@@ -182,6 +206,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     loc[l] = !fused[l] && l > 0 && !fused[l - 1] && explicit_mask && ((s->fuse_bwd >> (16 + l)) & 1) != 0;
   }
   const int T = s->T;
+  Probe probe = make_probe(s, true, stream);
   for (int so = T - 1; so >= -off[0]; --so) {
     for (int l = L - 1; l >= 0; --l) {
       const int u = so + off[l];
@@ -193,9 +218,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       auto pointwise = [&](int t) {      // consumes dh[l] / dc[l] of time t, writes dG of time t
         // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
-        return nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, (const char*)s->gates[l] + (size_t)t * gs, s->c[l] + (size_t)t * cs,
-                                                s->c[l] + (size_t)(t + 1) * cs, s->dh[l], s->dc[l], (char*)s->dG[l] + (size_t)t * dgs,
-                                                t == T - 1 && ((s->zero_dstate >> (2 * l)) & 1), stream);
+        probe.stamp(NINT_PROBE_POINTWISE, l, t, 0);
+        const int r = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, (const char*)s->gates[l] + (size_t)t * gs, s->c[l] + (size_t)t * cs,
+                                                       s->c[l] + (size_t)(t + 1) * cs, s->dh[l], s->dc[l], (char*)s->dG[l] + (size_t)t * dgs,
+                                                       t == T - 1 && ((s->zero_dstate >> (2 * l)) & 1), stream);
+        probe.stamp(NINT_PROBE_POINTWISE, l, t, 1);
+        return r;
       };
       // destination of the x columns of time t: the layer below's dh, or this time step's dx slab (written once)
       void* dx_dst = (l > 0) ? s->dh[l - 1]
@@ -222,7 +250,9 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           pw.tile_rows = 4;
           pw_done[l - 1] = u;
         }
+        probe.stamp(NINT_PROBE_DGRAD, l, u, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, loc[l] ? &pw : nullptr, stream);
+        probe.stamp(NINT_PROBE_DGRAD, l, u, 1);
       } else if (u == T) {
         rc = pointwise(T - 1);
       } else if (u >= 1) {
@@ -240,9 +270,13 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           pw.lo_dc_zero = u == T - 1 && ((s->zero_dstate >> (2 * (l - 1))) & 1);
           pw_done[l - 1] = u;
         }
+        probe.stamp(NINT_PROBE_FUSED, l, u, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream);
+        probe.stamp(NINT_PROBE_FUSED, l, u, 1);
       } else {
+        probe.stamp(NINT_PROBE_DGRAD, l, 0, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l], dx_dst, dh_prev, ow, nullptr, stream);
+        probe.stamp(NINT_PROBE_DGRAD, l, 0, 1);
       }
       if (rc != NINT_OK) return rc;
     }
@@ -257,7 +291,8 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     jobs[l] = WgJob{ly, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
                     s->has_init_state ? 0 : B};
   }
-  rc = nint_internal_conv_wgrad_multi(jobs, L, g, s->dtype, s->wg_partial, s->wg_partial_bytes, s->n_cu, stream);
+  rc = nint_internal_conv_wgrad_multi(jobs, L, g, s->dtype, s->wg_partial, s->wg_partial_bytes, s->n_cu, stream,
+                                      probe.buf ? &probe : nullptr);
   if (rc != NINT_OK) return rc;
   return NINT_OK;
 }

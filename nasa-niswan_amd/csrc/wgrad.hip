@@ -539,7 +539,7 @@ static int dispatch_wgrad(WgradArgs& a, const WgPart& w, int nblk, hipStream_t s
 // h_skip: the first h_skip images have an identically zero h source (h_{-1} = 0 of a sequence that starts from
 // the zero state, model.py:259-262): the h part skips them -- 1/T of its work.
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
-                                   size_t partial_bytes, int n_cu, void* stream) {
+                                   size_t partial_bytes, int n_cu, void* stream, Probe* probe) {
   if (!jobs || njobs < 1 || njobs > NINT_MAX_LAYERS || !g || !partial) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   const int es = dtype == NINT_BF16 ? 2 : 4;
@@ -566,6 +566,7 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
     a.k = ly->k; a.p = ly->k / 2;
     a.P = g->P; a.Wh = g->Wh;
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
+    if (probe) probe->stamp(NINT_PROBE_WGRAD, q, 0, 0);
     for (int part = 0; part < 2; ++part) {
       const WgPart& w = pl.part[part];
       WgSrc& S = a.s[pl.merged ? part : 0];
@@ -598,9 +599,12 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       E.waves = w.splits >= 64 ? 16 : 4;         // few large slabs: 4 waves share the splits; many small slabs: 16 waves
       if (E.waves * 64 > red_threads) red_threads = E.waves * 64;
     }
+    if (probe) probe->stamp(NINT_PROBE_WGRAD, q, 0, 1);
   }
+  if (probe) probe->stamp(NINT_PROBE_FOLD, 0, 0, 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blk), dim3(red_threads), 0, st, rt);
   NINT_LAUNCH_CHECK();
+  if (probe) probe->stamp(NINT_PROBE_FOLD, 0, 0, 1);
   return NINT_OK;
 }
 

@@ -54,58 +54,59 @@ class SlabBatch:
         ptrs, lev = ds._sources(dv)
         H, W = ds.grid
         t0 = (C.c_int * B)(*[int(t) for t in self.t0])
-        check(_lib.load().nint_preproc_fuse_pad_slab(ptrs, lev, len(lev), ptr(dv["mean"]), ptr(dv["std"]), t0, B,
-                                                     ptr(ws.xs), ws.Cxp0, eng.cfgs[0].k if eng.cfgs[0].xfold else 0, T, H, W,
-                                                     C.byref(ws.g), ds.mode, eng.dt,
-                                                     stream_ptr()), "nint_preproc_fuse_pad_slab")
+        lib = _lib.load()
+        rc = lib.nint_preproc_fuse_pad_slab(ptrs, lev, len(lev), ptr(dv["mean"]), ptr(dv["std"]), t0, B, ptr(ws.xs), ws.Cxp0,
+                                            eng.cfgs[0].k if eng.cfgs[0].xfold else 0, T, H, W, C.byref(ws.g), ds.mode, eng.dt,
+                                            stream_ptr())
+        if rc == _lib.NINT_E_LDS:
+            # a channel-row tile beyond the 160 KiB of LDS (hundreds of channels on a wide grid): the same values through
+            # the f32 tensor and the pack kernel, whose generic path has no such limit (bit-identical by construction:
+            # tests/test_gpu_train.py::test_slab_batch_is_bit_identical_to_preproc_then_pack)
+            X = torch.empty(B, T, Cc, Hp, Wp, dtype=torch.float32, device=self.device)
+            check(lib.nint_preproc_fuse_pad_batch(ptrs, lev, len(lev), ptr(dv["mean"]), ptr(dv["std"]), t0, B, ptr(X),
+                                                  T, H, W, Hp, Wp, ds.mode, stream_ptr()), "nint_preproc_fuse_pad_batch")
+            eng.pack_input(ws, X)
+            return
+        check(rc, "nint_preproc_fuse_pad_slab")
 
 
-class SyntheticE33OMA_CRNN(torch.utils.data.Dataset):
-    def __init__(self, period: str, species: str = "bcb", padding: Tuple[int, int] = (100, 154), in_channels: int = 5,
-                 sequence_length: int = 10, *, levels: int = 1, n_steps: int = 480, grid: Tuple[int, int] = (90, 144),
-                 pad_mode: str = "reference", device="cuda", seed: int = 0):
-        super().__init__()
-        assert species == "bcb", "only the BCB statistics ship with the reference"
+def reference_split(n_steps: int) -> Tuple[int, int]:
+    """(first validation step, first test step) of a record: the reference hard-codes 3023 / 3455 for its 4320-step (90 days x
+    48) file (dataset.py:589-612: 70 % / 10 % / 20 %); other record lengths get the same proportions."""
+    if n_steps == 4320:
+        return 3023, 3455
+    ntrain = int(round(0.7 * n_steps))
+    return ntrain, ntrain + int(round(0.1 * n_steps))
+
+
+class _ResidentRecord(torch.utils.data.Dataset):
+    """Everything after the file read of the reference's in-memory RNN dataset (dataset.py:587-634), on arrays that are
+    already in host memory: statistics over the training part, windows, period split, one upload of the record."""
+
+    def _setup(self, fields, yraw, period: str, padding, in_channels: int, sequence_length: int, levels: int,
+               grid: Tuple[int, int], pad_mode: str, device, pinned: bool = False):
         self.period, self.padding, self.seq_len, self.levels = period, tuple(padding) if padding else None, sequence_length, levels
         self.in_channels, self.grid, self.device = in_channels, tuple(grid), torch.device(device)
         self.mode = {"reference": 0, "reflect": 1}[pad_mode]
-        self.generic = in_channels != 3 * levels + 2       # static attributes (dataset.py:100-122) are out of scope
-        H, W = self.grid
-        rng = np.random.default_rng(seed)
-
-        def field(name, shape, positive=False):
-            m, s = STATS[name]
-            a = rng.standard_normal(shape).astype(np.float32)
-            if positive:   # precipitation / emission / concentration: non-negative, heavy right tail
-                a = np.maximum(0.0, m + s * (np.exp(0.9 * a) - 1.2)).astype(np.float32)
-            else:
-                a = (m + s * a).astype(np.float32)
-            return a
-        if self.generic:
-            # `in_channels` generic fields with the wind statistics; one source of in_channels "levels"
-            self.gen = field("u", (n_steps, in_channels, H, W))
-            self.fields = [("gen", self.gen)]
-        else:
-            self.u = field("u", (n_steps, levels, H, W))
-            self.v = field("v", (n_steps, levels, H, W))
-            self.w = field("w", (n_steps, levels, H, W))
-            self.prec = field("prec", (n_steps, H, W), True)
-            self.src = field("bc_src", (n_steps, H, W), True)
-            self.fields = [("u", self.u), ("v", self.v), ("w", self.w), ("prec", self.prec), ("src", self.src)]
-        self.yraw = field("bc_conc", (n_steps, levels, H, W), True)
-        ntrain = int(round(0.7 * n_steps))      # the reference hard-codes 3023 of 4320 steps (70 %)
-        nval = int(round(0.1 * n_steps))
+        self.fields, self.yraw, self.pinned = fields, yraw, pinned
+        n_steps = yraw.shape[0]
+        ntrain, ntest0 = reference_split(n_steps)
+        self.ntrain = ntrain
         # statistics over the training part of the record (dataset.py:589-596), one per fused channel
         chans = []
         for _, a in self.fields:
             chans += [a[:ntrain, l] for l in range(a.shape[1])] if a.ndim == 4 else [a[:ntrain]]
-        self.X_mean = np.array([c.mean() for c in chans], dtype=np.float32)
-        self.X_std = np.array([c.std() for c in chans], dtype=np.float32)
+        # (the reference's own expression -- a reduction over axes (0, 2, 3) of the stacked array -- so that the f32 summation
+        # order, and with it the last bit of the statistics, is the reference's)
+        Xs = np.stack(chans, axis=1)
+        self.X_mean = Xs.mean(axis=(0, 2, 3)).astype(np.float32)
+        self.X_std = Xs.std(axis=(0, 2, 3)).astype(np.float32)
+        del Xs
         self.y_mean = np.float32(self.yraw[:ntrain].mean())
         self.y_std = np.float32(self.yraw[:ntrain].std())
         nseq = n_steps - sequence_length + 1
-        lo, hi = {"train": (0, ntrain), "val": (ntrain, ntrain + nval), "test": (ntrain + nval, nseq)}[period]
-        self.first = np.arange(lo, min(hi, nseq))        # first time index of each window
+        lo, hi = {"train": (0, ntrain), "val": (ntrain, ntest0), "test": (ntest0, nseq)}[period]     # dataset.py:601-612
+        self.first = np.arange(min(lo, nseq), min(hi, nseq))        # first time index of each window
         self._dev = None
 
     def __len__(self):
@@ -122,8 +123,16 @@ class SyntheticE33OMA_CRNN(torch.utils.data.Dataset):
     def _device_arrays(self):
         if self._dev is None:
             d = self.device
-            self._dev = {name: torch.from_numpy(a).to(d) for name, a in self.fields}
-            self._dev.update(y=torch.from_numpy(self.yraw).to(d), mean=torch.from_numpy(self.X_mean).to(d),
+
+            def up(a):
+                """the ONE upload of a record array: page-locked staging + asynchronous copy when asked for (real arrays,
+                gigabytes: the copies of the six fields overlap each other and the host's staging of the next one)"""
+                t = torch.from_numpy(np.ascontiguousarray(a))
+                if self.pinned and d.type == "cuda":
+                    return t.pin_memory().to(d, non_blocking=True)
+                return t.to(d)
+            self._dev = {name: up(a) for name, a in self.fields}
+            self._dev.update(y=up(self.yraw), mean=torch.from_numpy(self.X_mean).to(d),
                              std=torch.from_numpy(self.X_std).to(d),
                              ymean=torch.full((self.levels,), float(self.y_mean), device=d),
                              ystd=torch.full((self.levels,), float(self.y_std), device=d))
@@ -173,3 +182,74 @@ class SyntheticE33OMA_CRNN(torch.utils.data.Dataset):
     def __getitem__(self, index):
         X, y = self.device_batch([index])
         return X[0], y[0]
+
+
+class SyntheticE33OMA_CRNN(_ResidentRecord):
+    def __init__(self, period: str, species: str = "bcb", padding: Tuple[int, int] = (100, 154), in_channels: int = 5,
+                 sequence_length: int = 10, *, levels: int = 1, n_steps: int = 480, grid: Tuple[int, int] = (90, 144),
+                 pad_mode: str = "reference", device="cuda", seed: int = 0):
+        super().__init__()
+        assert species == "bcb", "only the BCB statistics ship with the reference"
+        self.generic = in_channels != 3 * levels + 2       # static attributes (dataset.py:100-122) are out of scope
+        H, W = grid
+        rng = np.random.default_rng(seed)
+
+        def field(name, shape, positive=False):
+            m, s = STATS[name]
+            a = rng.standard_normal(shape).astype(np.float32)
+            if positive:   # precipitation / emission / concentration: non-negative, heavy right tail
+                a = np.maximum(0.0, m + s * (np.exp(0.9 * a) - 1.2)).astype(np.float32)
+            else:
+                a = (m + s * a).astype(np.float32)
+            return a
+        if self.generic:
+            # `in_channels` generic fields with the wind statistics; one source of in_channels "levels"
+            self.gen = field("u", (n_steps, in_channels, H, W))
+            fields = [("gen", self.gen)]
+        else:
+            self.u = field("u", (n_steps, levels, H, W))
+            self.v = field("v", (n_steps, levels, H, W))
+            self.w = field("w", (n_steps, levels, H, W))
+            self.prec = field("prec", (n_steps, H, W), True)
+            self.src = field("bc_src", (n_steps, H, W), True)
+            fields = [("u", self.u), ("v", self.v), ("w", self.w), ("prec", self.prec), ("src", self.src)]
+        yraw = field("bc_conc", (n_steps, levels, H, W), True)
+        self._setup(fields, yraw, period, padding, in_channels, sequence_length, levels, grid, pad_mode, device)
+
+
+class E33OMA90D_CRNN(_ResidentRecord):
+    """The reference's in-memory RNN dataset (dataset.py:551-637) on arrays the caller already holds -- what
+    `xr.open_dataset(root)[...].values` returns there (xarray / NetCDF are not on the hot path and not rebuilt):
+
+        ds = E33OMA90D_CRNN.from_arrays(u, v, omega, prec, src, conc, period="train", padding=(100, 154), sequence_length=48)
+
+    u, v, omega, conc: (n_steps, H, W) = the reference's `isel(level=0)` fields, or (n_steps, L, H, W) for the level-fused
+    extension; prec, src: (n_steps, H, W).  Statistics over the first 3023 steps and the 3023 / 3455 split when the record has
+    the reference's 4320 steps (dataset.py:587-612), the same 70 / 10 / 20 % otherwise; windows X[i] = steps [i, i+T), target =
+    the tracer at step i+T-1 (dataset.py:598-599,614-616).  The record is uploaded ONCE (page-locked staging, asynchronous
+    copies) and stays resident in HBM; `device_batch` / `slab_batch` / `__getitem__` are those of the synthetic dataset."""
+
+    def __init__(self, *a, **k):
+        raise TypeError("the NetCDF reader of the reference is out of scope (SURVEY.md section 2): use E33OMA90D_CRNN.from_arrays")
+
+    @classmethod
+    def from_arrays(cls, u, v, omega, prec, src, conc, *, period: str = "train", species: str = "bcb",
+                    padding: Tuple[int, int] = (100, 154), sequence_length: int = 10, pad_mode: str = "reference",
+                    device="cuda", pinned: bool = True):
+        self = cls.__new__(cls)
+        torch.utils.data.Dataset.__init__(self)
+        f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        u, v, omega, prec, src, conc = (f32(a) for a in (u, v, omega, prec, src, conc))
+        lev = lambda a: a if a.ndim == 4 else a[:, None]
+        u, v, omega, conc = lev(u), lev(v), lev(omega), lev(conc)
+        n, L, H, W = u.shape
+        for name, a in (("v", v), ("omega", omega), ("conc", conc)):
+            if a.shape != (n, L, H, W):
+                raise ValueError(f"{name}: expected {(n, L, H, W)}, got {a.shape}")
+        for name, a in (("prec", prec), ("src", src)):
+            if a.shape != (n, H, W):
+                raise ValueError(f"{name}: expected {(n, H, W)}, got {a.shape}")
+        self.species, self.generic = species, False
+        fields = [("u", u), ("v", v), ("w", omega), ("prec", prec), ("src", src)]          # fusion order dataset.py:584
+        self._setup(fields, conc, period, padding, 3 * L + 2, sequence_length, L, (H, W), pad_mode, device, pinned=pinned)
+        return self

@@ -16,9 +16,13 @@ from ._lib import NINT_BF16, NINT_F32, NintGeom, NintLayer, NintSeq, check, ptr,
 # engines built afterwards (nint_layer.tile_rows) -- how the tests run both heights on every shape
 FORCE_TILE_ROWS = 0
 # Thin first-layer inputs (the reference's Conv2d(5+64 -> 256, k=5), model.py:207-211) are fed HORIZONTALLY FOLDED
-# when that lowers the number of MFMA K-steps (nint_xfold_pays): 5 x-steps instead of 25.  False keeps the plain
+# when that lowers the number of MFMA K-steps (nint_xfold_pays): 5 x-steps instead of 25.  (Any channel count and grid width
+# packs: row tiles up to 160 KiB go through the LDS-tiled pack kernel, wider ones through the per-element one.)  False keeps the plain
 # channel-padded layout for engines built afterwards (tests run both).
 XFOLD = True
+# nint_layer.wide of engines built afterwards: 0 = the library picks the gate / dgrad kernel family per launch shape, 1 = always
+# the 4-wave kernels (csrc/conv_igemm.hip), 2 = the 8-wave LDS-weight kernel (csrc/conv_wide.hip) wherever it is instantiated
+FORCE_WIDE = 0
 FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
 
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
@@ -143,6 +147,7 @@ class SeqEngine:
             ly.Wf, ly.Wd, ly.bias_p = self.Wf[-1].data_ptr(), self.Wd[-1].data_ptr(), self.bias_p[-1].data_ptr()
             self.layers.append(ly)
             ly.tile_rows = FORCE_TILE_ROWS
+            ly.wide = FORCE_WIDE
             # the layers' split-K slabs sit side by side in one workspace: one launch folds them all
             wg_bytes += (self.lib.nint_wgrad_workspace_bytes(C.byref(ly), self.dt, self.n_cu) + 255) // 256 * 256
         # shapes the weight-gradient kernel has no instantiation for: known NOW, reported at the first training
@@ -206,6 +211,7 @@ class SeqEngine:
         for ws in self.pool.setdefault(key, []):
             if not ws.in_use:
                 ws.in_use = True
+                ws.seq.probe, ws.seq.probe_mask, ws.seq.probe_slots = None, 0, 0     # (a trainer's timing probes do not outlive its step)
                 return ws
         ws = Workspace(self, B, T, H, W, train, has_init)
         for l, ly in enumerate(self.layers):

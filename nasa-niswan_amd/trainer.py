@@ -39,6 +39,7 @@ class FusedTrainer:
         # [0..4] pooled: sum d^2, sum |d|, sum y, sum y^2, n; [5..7] per call: sum loss, sum r2_score, calls
         self.stats = torch.zeros(NINT_LOSS_STATS, dtype=torch.float64, device=dev)
         self._dpred = None
+        self._probe = (None, 0)
         import torch.distributed as dist
         self.dist = dist
         self.pg = process_group
@@ -54,6 +55,12 @@ class FusedTrainer:
         if self.distributed:
             # identical initial weights on every rank (the reference seeds identically, utils.py:77-88)
             dist.broadcast(self.flat.data, src=0, group=process_group)
+
+    def set_probe(self, buf: Optional[torch.Tensor], mask: int = 0):
+        """In-step timing probes (nint_seq.probe, include/nint.h): `buf` = int64/uint64 device tensor of 2*slots words that
+        the following step() calls fill with {tag, 100 MHz timestamp} pairs around every launch whose kind is in `mask`;
+        None switches them off.  Diagnostic: bench.py prices the kernels INSIDE the step with it."""
+        self._probe = (buf, int(mask) if buf is not None else 0)
 
     # ------------------------------------------------------------------ pieces
     def forward_loss(self, X: torch.Tensor, y: torch.Tensor, train: bool = True):
@@ -88,6 +95,9 @@ class FusedTrainer:
         B, T, _, H, W = X.shape
         L = m.num_layers
         ws = eng.acquire(B, T, H, W, True, False)
+        pb, pm = self._probe
+        ws.seq.probe = pb.data_ptr() if pb is not None else None
+        ws.seq.probe_mask, ws.seq.probe_slots = pm, (pb.numel() // 2 if pb is not None else 0)
         eng.pack_weights([c.conv.weight for c in m.layers], [c.conv.bias for c in m.layers])
         eng.forward(ws, X)
         O = m.conv.weight.shape[0]

@@ -108,3 +108,20 @@ def preproc_sample(u, v, w, prec, src, mean, std, padding=None, mode: str = "ref
     if padding:
         x = padding_data_4d(x, padding, mode)
     return x.astype(np.float32)
+
+
+def inmemory_rnn_dataset(X1, X2, X3, X4, X5, y, period: str, seq_len: int):
+    """dataset.py:584-616 (`E33OMA90D_CRNN._get_data`) on arrays instead of the NetCDF file: stack, statistics over the first
+    3023 steps, z-score, sliding windows, target lag, 3023 / 3455 split.  Returns (X (n, T, 5, H, W), y (n, H, W), X_mean, X_std,
+    y_mean, y_std) exactly as the reference's attributes hold them (before padding)."""
+    Xs = np.stack([X1, X2, X3, X4, X5], axis=1)                             # dataset.py:584
+    y_mean = y[:3023, ...].mean().reshape(-1, 1, 1)                         # :587
+    y_std = y[:3023, ...].std().reshape(-1, 1, 1)
+    X_mean = Xs[:3023, ...].mean(axis=(0, 2, 3)).reshape(-1, 1, 1)          # :590
+    X_std = Xs[:3023, ...].std(axis=(0, 2, 3)).reshape(-1, 1, 1)
+    Xs = (Xs - X_mean) / X_std                                              # :593
+    y = (y - y_mean) / y_std
+    X = np.lib.stride_tricks.sliding_window_view(Xs, (seq_len, *Xs.shape[1:])).squeeze()     # :614-616
+    y = y[seq_len - 1:]                                                     # :599
+    sl = {"train": slice(None, 3023), "val": slice(3023, 3455), "test": slice(3455, None)}[period]   # :601-612
+    return X[sl], y[sl], X_mean, X_std, y_mean, y_std

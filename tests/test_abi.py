@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -27,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in nint.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.nint_version() == _lib.NINT_VERSION == 106
+    assert lib.nint_version() == _lib.NINT_VERSION == 107
     assert lib.nint_kc(0) == 16 and lib.nint_kc(1) == 32
     assert lib.nint_error_string(-2).decode().startswith("nint:")
 
@@ -36,14 +37,16 @@ def test_struct_layout_matches_header(tmp_path):
     """Compile a tiny C program against nint.h and compare sizeof/offsetof with ctypes."""
     from nasa_niswan_amd import _lib
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nint.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nint.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(nint_geom),sizeof(nint_layer),sizeof(nint_seq),offsetof(nint_layer,Wf),offsetof(nint_seq,xs),'
-                    'offsetof(nint_seq,dW),offsetof(nint_seq,wg_partial_bytes));return 0;}\n')
+                    'offsetof(nint_seq,dW),offsetof(nint_seq,wg_partial_bytes),offsetof(nint_layer,wide),'
+                    'offsetof(nint_seq,probe),offsetof(nint_seq,probe_slots));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.NintGeom), C.sizeof(_lib.NintLayer), C.sizeof(_lib.NintSeq), _lib.NintLayer.Wf.offset,
-            _lib.NintSeq.xs.offset, _lib.NintSeq.dW.offset, _lib.NintSeq.wg_partial_bytes.offset]
+            _lib.NintSeq.xs.offset, _lib.NintSeq.dW.offset, _lib.NintSeq.wg_partial_bytes.offset, _lib.NintLayer.wide.offset,
+            _lib.NintSeq.probe.offset, _lib.NintSeq.probe_slots.offset]
     assert got == want
 
 
@@ -144,6 +147,17 @@ def test_library_reads_no_environment_and_owns_no_streams():
     for sym in ("getenv", "secure_getenv", "hipStreamCreate", "hipStreamCreateWithFlags", "hipStreamCreateWithPriority",
                 "hipEventCreate", "hipEventCreateWithFlags"):
         assert not re.search(rf"\b{sym}\b", und), f"libnint_hip.so imports {sym}"
+
+
+def test_binding_picks_the_product_library_whatever_the_environment_says():
+    """nothing in the environment can swap the library the package loads (round 2 had a NINT_LIB
+    override for experiment builds; diagnostic tools now pass an explicit path to load())."""
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['NINT_LIB'] = '/nonexistent/libother.so';"
+            "from nasa_niswan_amd import _lib; print(_lib.LIB_PATH); _lib.load()") % ROOT
+    out = subprocess.check_output([sys.executable, "-c", code], text=True).strip()
+    assert out.endswith(os.path.join("nasa-niswan_amd", "libnint_hip.so"))
+    src = open(os.path.join(ROOT, "nasa-niswan_amd", "_lib.py")).read()
+    assert "os.environ" not in src and "getenv" not in src
 
 
 def test_graft_entry_build_passes():

@@ -1,0 +1,81 @@
+"""CPU-only checks of bench.py's command line: `--gpus N` without a launcher starts its own N ranks as child
+processes (the driver's invocation form for N = 1 must also work for N > 1), strong / weak
+batch arithmetic, and the parser of the in-step timing probes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_gpus_n_builds_the_torchrun_child_command(monkeypatch):
+    bench = _bench()
+    seen = {}
+
+    class FakeProc:
+        stdout = iter(['{"metric": "x"}\n', "launcher chatter\n"])
+
+        def wait(self):
+            return 7
+
+    def fake_popen(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw["env"]
+        return FakeProc()
+
+    monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
+    argv = ["--gpus", "4", "--steps", "3", "--scaling", "strong"]
+    rc = bench.spawn_ranks(bench.parse_args(argv), argv)
+    assert rc == 7                                            # the child's exit code is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.timeout(300)
+def test_gpus_2_really_starts_two_ranks_and_returns_their_failure_here():
+    """No GPU in this container: both ranks must get as far as the device check and refuse (there is no CPU path), and the
+    parent must hand their failure back as its own exit code -- after having decided to spawn from argv alone."""
+    env = dict(os.environ, MASTER_PORT="29611")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--master-port", "29611"], capture_output=True, text=True, env=env, timeout=280)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("meant for the CPU-only container")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+
+
+def test_probe_parser_pairs_stamps_and_subtracts_the_calibration():
+    bench = _bench()
+    T63 = 1 << 63
+
+    def tag(kind, layer, t, end):
+        v = kind | layer << 8 | t << 16 | end << 31 | T63
+        return v - (1 << 64)                                   # as the int64 tensor holds it
+
+    w = np.zeros(64, dtype=np.int64)
+    rows = [(0, 0, 0, 0, 1000), (0, 0, 0, 1, 1300),            # calibration pair: 3 us
+            (1, 0, 0, 0, 2000), (1, 0, 0, 1, 12300),           # gate layer 0 t=0: 103 us - 3
+            (1, 2, 5, 0, 20000), (1, 2, 5, 1, 22900)]          # gate layer 2 t=5: 29 us - 3
+    for i, (k, l, t, e, ticks) in enumerate(rows):
+        w[2 * i], w[2 * i + 1] = tag(k, l, t, e), ticks
+    d = bench.probe_durations(w, np.zeros(8, dtype=np.int64))
+    assert d[(1, 0)] == [(0, 100.0)] and d[(1, 2)] == [(5, 26.0)] and d["cal_us"] == [3.0]
+
+
+def test_strong_scaling_divides_the_global_batch():
+    bench = _bench()
+    a = bench.parse_args(["--gpus", "8", "--scaling", "strong"])
+    assert a.batch == 8 and a.scaling == "strong"             # 8 in all -> 1 per GPU (main() divides by the world size)
+    assert bench.parse_args([]).scaling == "weak" and bench.parse_args([]).long_steps == 200

@@ -1,0 +1,224 @@
+"""The path bench.py times -- `FusedTrainer.step` (fused head/loss pass, gradients written straight into the flat bucket,
+flat Adam) -- against the CPU oracle AT THE BENCH'S OWN SIZE (cfg1-20level: 100x154, T=12, C=62, head out 20), B=2, in f32
+and bf16, fed both ways the product feeds it: a (B,T,C,Hp,Wp) tensor and a dataset.SlabBatch that the preproc kernel
+writes straight into the input slab.  (tests/test_gpu_fullsize.py checks the autograd-Function path on the same shape;
+the small-grid suites check the trainer on <= 32x32 grids.)
+
+And BASELINE configs[3] at its stated seq_len = 24 with B = 2: the first shapes whose slabs exceed 2^31 bytes (gate stash of
+one layer 2.78 GB).  The CPU oracle would need ~50 TFLOP for that case, so it is checked through size-independent
+properties against the launches that ARE oracle-checked at T = 2 (test_gpu_fullsize.py::test_cfg3_full_grid_vs_oracle):
+the recurrence is the same function at every step, so the last two steps of the T=24 run (slab images 44..49, past
+2^31 bytes) must equal, bit for bit, a T=2 run started from the T=24 run's state after step 21 -- forward slabs, gate
+stash AND the dG slabs of the BPTT; the weight gradient over all 48 images must equal the sum of two 24-image reductions
+(second half addressed through a base pointer past 2^31); and everything is bitwise reproducible run to run.
+
+Tolerances: f32 loss 2e-6 relative, gradients max-abs <= 1e-3 max|g| (measured ~1e-6); bf16 rel-L2 <= 2e-2."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG1 = dict(C=62, hidden=[64, 32, 16], ks=[5, 3, 3], out=20, T=12, Hp=100, Wp=154, halo=(5, 5), grid=(90, 144))
+_ORACLE = {}
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import nasa_niswan_amd as p
+    p.load_library()
+    return p
+
+
+def _case(kind):
+    """(params, X for the oracle (CPU f32), X for the product (tensor or SlabBatch), y (CPU), oracle results) -- the oracle
+    runs once per input kind and serves both storage types."""
+    from oracle import convlstm_oracle as O
+    from oracle import preproc_oracle as PO
+    c = CFG1
+    if kind in _ORACLE:
+        return _ORACLE[kind]
+    params = O.synth_params(c["C"], c["hidden"], c["ks"], 3, out_channels=c["out"], seed=7)
+    B = 2
+    if kind == "tensor":
+        rng = np.random.default_rng(21)
+        X = torch.from_numpy(rng.standard_normal((B, c["T"], c["C"], c["Hp"], c["Wp"])).astype(np.float32))
+        y = torch.from_numpy(rng.standard_normal((B, c["out"], *c["grid"])).astype(np.float32))
+        feed = X.cuda()
+    else:
+        from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
+        ds = SyntheticE33OMA_CRNN("train", padding=(c["Hp"], c["Wp"]), in_channels=c["C"], sequence_length=c["T"], levels=20,
+                                  n_steps=40, grid=c["grid"], device="cuda", seed=5)
+        idx = [3, 11]
+        feed, yd = ds.slab_batch(idx)
+        # the oracle's own inputs: CPU preproc restatement (dataset.py:520-536, 61-98) of the same windows
+        X = torch.stack([torch.from_numpy(PO.preproc_sample(*ds.window(i)[0], ds.X_mean, ds.X_std, (c["Hp"], c["Wp"]), "reference"))
+                         for i in idx])
+        y = torch.stack([torch.from_numpy((ds.window(i)[1] - ds.y_mean) / ds.y_std) for i in idx]).float()
+        assert float((yd.cpu() - y).abs().max()) <= 1e-5 * float(y.abs().max())
+    p1, _, loss, _, grads = O.train_step(params, None, X, y, lr=1e-3, betas=(0.5, 0.999), halo=c["halo"])
+    _ORACLE[kind] = (params, feed, y, loss, grads, p1)
+    return _ORACLE[kind]
+
+
+@pytest.mark.parametrize("kind", ["tensor", "slab"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_trainer_step_at_bench_size_vs_oracle(pkg, dtype, kind):
+    """train.py:96-110 through FusedTrainer.step on the bench workload: loss, the 8 gradients as the flat bucket holds
+    them, and the weights after one Adam step."""
+    from nasa_niswan_amd.trainer import FusedTrainer
+    c = CFG1
+    params, feed, y, oloss, ograds, p1 = _case(kind)
+    net = pkg.ConvLSTM(c["C"], c["hidden"], c["ks"], 3, out_channels=c["out"], compute_dtype=dtype).cuda()
+    net.load_state_dict(params)
+    tr = FusedTrainer(net, lr=1e-3, betas=(0.5, 0.999), halo=c["halo"])
+    loss = float(tr.step(feed, y.cuda()))
+    tol_loss = 2e-6 if dtype == "f32" else 2e-2
+    print(f"  {dtype}/{kind}: loss {loss:.7f} oracle {oloss:.7f}")
+    assert abs(loss - oloss) <= tol_loss * abs(oloss), (loss, oloss)
+    for i, (k, p) in enumerate(net.named_parameters()):
+        a, b = tr.flat.grad_view(i).cpu().double().reshape(-1), ograds[k].double().reshape(-1)
+        assert torch.isfinite(a).all(), k
+        if dtype == "f32":
+            err, ref = float((a - b).abs().max()), float(b.abs().max())
+            print(f"    grad.{k}: max abs err {err:.2e} (ref max {ref:.2e})")
+            assert err <= 1e-3 * ref + 1e-9, (k, err, ref)
+        else:
+            r = float((a - b).norm() / (b.norm() + 1e-30))
+            print(f"    grad.{k}: rel-L2 {r:.2e}")
+            assert r <= 2e-2, (k, r)
+    # one Adam step moves every weight by lr * g / (|g| + eps): +-lr unless the gradient is ~0, where a last-bit sign
+    # difference moves it by up to 2 lr; so: bounded by 2 lr everywhere, and equal to the oracle's step almost everywhere
+    lr = 1e-3
+    for k, v in net.state_dict().items():
+        d = (v.cpu() - p1[k]).abs()
+        frac = float((d > 0.05 * lr).float().mean())
+        print(f"    {k}: max |dW| {float(d.max()):.2e}, weights off by > lr/20: {100 * frac:.3f} %")
+        assert float(d.max()) <= 2.001 * lr + 1e-7, (k, float(d.max()))
+        # (tiny tensors -- the 20 head biases -- get one flip of slack)
+        assert frac <= (2e-4 if dtype == "f32" else 2e-2) + 1.0 / d.numel(), (k, frac)
+
+
+def test_bench_final_loss_at_b2_f32_is_the_oracles(pkg):
+    """bench.py prints `final_loss` after warm-up + timed steps of FusedTrainer.step on seeded data; the same loop at
+    B=2 in f32 (3 steps) must land on the oracle's loss trajectory, step by step."""
+    from nasa_niswan_amd.trainer import FusedTrainer
+    from oracle import convlstm_oracle as O
+    c = CFG1
+    params, feed, y, oloss, _, _ = _case("tensor")
+    net = pkg.ConvLSTM(c["C"], c["hidden"], c["ks"], 3, out_channels=c["out"], compute_dtype="f32").cuda()
+    net.load_state_dict(params)
+    tr = FusedTrainer(net, lr=1e-3, betas=(0.5, 0.999), halo=c["halo"])
+    p, st, X = params, None, feed.cpu()
+    for step in range(3):
+        loss = float(tr.step(feed, y.cuda()))
+        p, st, ol, _, _ = O.train_step(p, st, X, y, lr=1e-3, betas=(0.5, 0.999), halo=c["halo"])
+        print(f"  step {step}: loss {loss:.7f} oracle {ol:.7f}")
+        # (after the first update the two weight sets differ where a ~0 gradient flipped sign: 1e-4 relative on the loss)
+        assert abs(loss - ol) <= (2e-6 if step == 0 else 2e-4) * abs(ol)
+
+
+# ------------------------------------------------------------------------------------------ configs[3] at T = 24, B = 2
+def _u8(t):
+    return t.view(torch.uint8)
+
+
+def test_cfg3_seq24_batch2_slabs_past_2g_prefix_and_linearity(pkg):
+    from nasa_niswan_amd.engine import LayerCfg, SeqEngine
+    from nasa_niswan_amd import _lib
+    lib = _lib.load()
+    Cin, hidden, ks, out, T, B, H, W = 62, [128, 128, 128], [3, 3, 3], 20, 24, 2, 190, 298
+    torch.manual_seed(11)
+    eng = SeqEngine([LayerCfg(Cin if l == 0 else hidden[l - 1], hidden[l], ks[l]) for l in range(3)], "bf16", "cuda")
+    Ws = [torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * 0.03 for c in eng.cfgs]
+    bs = [torch.randn(4 * c.Ch, device="cuda") * 0.1 for c in eng.cfgs]
+    w_head = torch.randn(out, hidden[-1], 1, 1, device="cuda") * 0.1
+    eng.pack_weights(Ws, bs)
+    X = torch.randn(B, T, Cin, H, W, device="cuda")
+    dpred = torch.randn(B, out, H, W, device="cuda") * 1e-3
+    L = 3
+    es = eng.es
+    st = None
+
+    def run_long():
+        ws = eng.acquire(B, T, H, W, True, False)
+        eng.forward(ws, X)
+        eng.head_backward(ws, w_head, dpred)
+        dWs, dbs, _ = eng.backward(ws, False, zero_state_grads=range(L))
+        torch.cuda.synchronize()
+        return ws, dWs, dbs
+
+    ws, dWs, dbs = run_long()
+    g = ws.g
+    halo_px, comp_px = g.Hh * g.Wh, H * W
+    assert T * B * comp_px * 4 * 128 * es > 2 ** 31 and (T + 1) * B * halo_px * 128 * es < 2 ** 33      # the case is what it says
+    keep = {"h": [_u8(t).clone() for t in ws.h], "c": [t.clone() for t in ws.c], "gates": [_u8(t).clone() for t in ws.gates],
+            "dG": [_u8(t).clone() for t in ws.dG], "dW": [t.clone() for t in dWs], "db": [t.clone() for t in dbs]}
+    assert all(bool(torch.isfinite(t).all()) for t in keep["dW"])
+    eng.release(ws)
+
+    # (1) run-to-run determinism of the whole pass at this size
+    ws_b, dWs_b, dbs_b = run_long()
+    assert ws_b is ws
+    for l in range(L):
+        assert torch.equal(_u8(ws.h[l]), keep["h"][l]) and torch.equal(ws.c[l], keep["c"][l]), l
+        assert torch.equal(_u8(ws.gates[l]), keep["gates"][l]) and torch.equal(_u8(ws.dG[l]), keep["dG"][l]), l
+        assert torch.equal(dWs_b[l], keep["dW"][l]) and torch.equal(dbs_b[l], keep["db"][l]), l
+
+    # (2) the last two steps == a T=2 run from the state after step 21 (slot 22), bit for bit
+    T2, s0 = 2, T - 2
+    h0, c0 = [], []
+    for l, cfg in enumerate(eng.cfgs):
+        h0.append(eng.h_last(ws, l, slot=s0))
+        cc = torch.empty(B, cfg.Ch, H, W, dtype=torch.float32, device="cuda")
+        _lib.check(lib.nint_unpack_compact(C.c_void_p(ws.c_view(eng, l, s0)), C.c_void_p(cc.data_ptr()), B, cfg.Ch, cfg.padded(eng.kc)[2],
+                                           H, W, _lib.NINT_F32, st), "unpack c")
+        c0.append(cc)
+    ws2 = eng.acquire(B, T2, H, W, True, True)
+    eng.forward(ws2, X[:, s0:].contiguous(), h0, c0)
+    eng.head_backward(ws2, w_head, dpred)
+    eng.backward(ws2, False, zero_state_grads=range(L))
+    torch.cuda.synchronize()
+    for l, cfg in enumerate(eng.cfgs):
+        Chp, Ch16 = cfg.padded(eng.kc)[2], cfg.padded(eng.kc)[1]
+        hs, cs = B * halo_px * Chp * es, B * comp_px * Chp
+        gs, dgs = B * comp_px * 4 * Ch16 * es, B * halo_px * 4 * Ch16 * es
+        for t in range(T2):
+            a = _u8(ws2.h[l])[(t + 1) * hs:(t + 2) * hs]
+            b = keep["h"][l][(s0 + t + 1) * hs:(s0 + t + 2) * hs]
+            assert torch.equal(a, b), ("h", l, t)
+            assert torch.equal(ws2.c[l][(t + 1) * cs:(t + 2) * cs], keep["c"][l][(s0 + t + 1) * cs:(s0 + t + 2) * cs]), ("c", l, t)
+            assert torch.equal(_u8(ws2.gates[l])[t * gs:(t + 1) * gs], keep["gates"][l][(s0 + t) * gs:(s0 + t + 1) * gs]), ("gates", l, t)
+            assert torch.equal(_u8(ws2.dG[l])[t * dgs:(t + 1) * dgs], keep["dG"][l][(s0 + t) * dgs:(s0 + t + 1) * dgs]), ("dG", l, t)
+    eng.release(ws2)
+
+    # (3) weight gradient of layer 1 over all 48 images == sum of two 24-image reductions (f32 split-K order differs: 1e-4)
+    l = 1
+    ly, cfg = eng.layers[l], eng.cfgs[l]
+    Cxp, Ch16, Chp = cfg.padded(eng.kc)
+    dgs1, xs1, hs1 = halo_px * 4 * Ch16 * es, halo_px * Cxp * es, halo_px * Chp * es
+    x_all = ws.h[l - 1].data_ptr() + B * xs1            # h^{l-1}_t = slab t+1
+    part = eng.wg_partial
+
+    def wgrad(n0, n):
+        dW = torch.empty(4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k, device="cuda")
+        db = torch.empty(4 * cfg.Ch, device="cuda")
+        _lib.check(lib.nint_conv_wgrad(C.byref(ly), C.byref(g), eng.dt, n, C.c_void_p(ws.dG[l].data_ptr() + n0 * dgs1),
+                                       C.c_void_p(x_all + n0 * xs1), C.c_void_p(ws.h[l].data_ptr() + n0 * hs1),
+                                       C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()), C.c_void_p(part.data_ptr()),
+                                       part.numel() * 4, eng.n_cu, st), "nint_conv_wgrad")
+        return dW, db
+    n = T * B
+    dW_all, db_all = wgrad(0, n)
+    dW_a, db_a = wgrad(0, n // 2)
+    dW_b, db_b = wgrad(n // 2, n // 2)
+    torch.cuda.synchronize()
+    for whole, parts in ((dW_all, dW_a + dW_b), (db_all, db_a + db_b)):
+        err, ref = float((whole - parts).abs().max()), float(whole.abs().max())
+        print(f"  wgrad 48 images vs 24 + 24: max abs diff {err:.2e} (max {ref:.2e})")
+        assert ref > 0 and err <= 1e-4 * ref
+    eng.release(ws_b)

@@ -8,7 +8,7 @@ The oracle (plain PyTorch CPU ops, oracle/convlstm_oracle.py) costs a few second
 host cores (bench.py's cpu_baseline runs the same B=2 train step in ~3.6 s).
 
 Tolerances (the suite's standing ones): f32 mode pred rtol 1e-4 / atol 1e-5, loss 2e-6 relative, gradients
-max-abs <= 1e-3 * max|g|; bf16 mode rel-L2 <= 2e-2 (pred, loss) / 5e-2 (gradients)."""
+max-abs <= 1e-3 * max|g|; bf16 mode rel-L2 <= 2e-2 (pred, loss and gradients; measured: 1e-4 / 6e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -75,7 +75,7 @@ def _check(res, dtype):
         else:
             r = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
             print(f"  {k}: rel-L2 {r:.2e}")
-            assert r <= (2e-2 if k in ("pred", "loss") else 5e-2), (k, r)
+            assert r <= 2e-2, (k, r)      # gradients measured <= 6.2e-3 at full size
 
 
 CFG1 = dict(C=62, hidden=[64, 32, 16], ks=[5, 3, 3], out=20, T=12, Hp=100, Wp=154, halo=(5, 5), grid=(90, 144))
@@ -90,8 +90,8 @@ def test_bench_workload_full_size_train_step_vs_oracle(pkg, dtype):
 
 
 def test_bench_workload_full_size_batch8_forward_vs_oracle(pkg):
-    """The launch shape the bench times (B=8: 8 x 13 x 10 = 1040 workgroups for the layer-0 gate kernel),
-    forward only, f32."""
+    """The launch shape the bench times (B=8: 8 x (12 x 10 full tiles + 5 merged strip tiles) = 1000 workgroups for the
+    4-wave layer-0 gate kernel), forward only, f32."""
     from oracle import convlstm_oracle as O
     c = CFG1
     params = O.synth_params(c["C"], c["hidden"], c["ks"], 3, out_channels=c["out"], seed=2)

@@ -131,3 +131,66 @@ def test_fused_and_classic_schedules_agree(pkg):
             engine.FUSE_BWD = 0
     for a, b in zip(res[1], res[2]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("mode", [1, 2, 0x40000404, 0x40000003])
+def test_schedules_with_a_given_initial_state_multi_layer(pkg, mode):
+    """nint_seq.has_init_state with fused layers BELOW the top (the combination the model suite only reaches with one
+    layer): at u == 0 a fused layer runs the plain dgrad and stores d/dh_init into a dh buffer that, for l < L-1, also
+    carried the upper layer's x columns.  Three layers, T = 3, given h0 / c0 per layer; every weight / bias gradient, the input
+    gradient and d/dh_init, d/dc_init of every layer against the oracle's autograd (model.py:253-271 from a given state)."""
+    from nasa_niswan_amd import engine
+    from nasa_niswan_amd.engine import LayerCfg, SeqEngine
+    from oracle import convlstm_oracle as O
+    Cin, hidden, ks, B, T, H, W = 5, [16, 8, 8], [3, 3, 3], 2, 3, 11, 19
+    L = 3
+    params = O.synth_params(Cin, hidden, ks, L, seed=9)
+    rng = np.random.default_rng(9)
+    X = torch.from_numpy(rng.standard_normal((B, T, Cin, H, W)).astype(np.float32))
+    h0 = [torch.from_numpy(rng.standard_normal((B, c, H, W)).astype(np.float32)) * 0.5 for c in hidden]
+    c0 = [torch.from_numpy(rng.standard_normal((B, c, H, W)).astype(np.float32)) * 0.5 for c in hidden]
+    wgt = torch.from_numpy(rng.standard_normal((B, 1, H, W)).astype(np.float32))
+    # oracle
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Xo = X.clone().requires_grad_(True)
+    h0o = [t.clone().requires_grad_(True) for t in h0]
+    c0o = [t.clone().requires_grad_(True) for t in c0]
+    po = O.convlstm_forward(Xo, leaf, h0=h0o, c0=c0o)
+    (po * wgt).sum().backward()
+    engine.FUSE_BWD = mode
+    try:
+        for dtype in ("f32", "bf16"):
+            eng = SeqEngine([LayerCfg(Cin if l == 0 else hidden[l - 1], hidden[l], ks[l]) for l in range(L)], dtype, "cuda")
+            ws = eng.acquire(B, T, H, W, True, True)
+            assert ws.seq.has_init_state == 1 and ws.seq.fuse_bwd == mode
+            eng.pack_weights([params[f"layers.{l}.conv.weight"].cuda() for l in range(L)],
+                             [params[f"layers.{l}.conv.bias"].cuda() for l in range(L)])
+            eng.forward(ws, X.cuda(), [t.cuda() for t in h0], [t.cuda() for t in c0])
+            w_head, b_head = params["conv.weight"].cuda(), params["conv.bias"].cuda()
+            pred = eng.head_forward(ws, w_head, b_head)
+            eng.head_backward(ws, w_head, wgt.cuda().expand(B, 1, H, W).contiguous())
+            for l in range(L):
+                if l < L - 1:
+                    eng.set_state_grads(ws, l, None, None)
+                else:
+                    ws.dc[l].zero_()
+            dWs, dbs, dx = eng.backward(ws, True)
+            res = {"pred": (pred.cpu(), po.detach()), "dX": (dx.cpu(), Xo.grad)}
+            for l in range(L):
+                res[f"dW{l}"] = (dWs[l].cpu(), leaf[f"layers.{l}.conv.weight"].grad)
+                res[f"db{l}"] = (dbs[l].cpu(), leaf[f"layers.{l}.conv.bias"].grad)
+                dh, dc = eng.state_grads(ws, l)
+                res[f"dh0_{l}"] = (dh.cpu(), h0o[l].grad)
+                res[f"dc0_{l}"] = (dc.cpu(), c0o[l].grad)
+            eng.release(ws)
+            for k, (a, b) in res.items():
+                a, b = a.double(), b.double()
+                assert torch.isfinite(a).all(), (dtype, k)
+                if dtype == "f32":
+                    err, ref = float((a - b).abs().max()), float(b.abs().max())
+                    assert err <= 1e-3 * ref + 1e-5, (dtype, k, err, ref)
+                else:
+                    r = float((a - b).norm() / (b.norm() + 1e-30))
+                    assert r <= 2e-2, (dtype, k, r)
+    finally:
+        engine.FUSE_BWD = 0

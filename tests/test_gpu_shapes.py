@@ -51,7 +51,7 @@ def check(res, dtype):
         else:
             r = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
             print(f"  {k}: rel-L2 {r:.2e}")
-            assert r <= 5e-2, (k, r)
+            assert r <= 2e-2, (k, r)
 
 
 CASES = {
@@ -62,6 +62,10 @@ CASES = {
     "cfg3-reduced (3 x hidden 128, k3)": (6, [128, 128, 128], [3, 3, 3], 1, 1, 2, 10, 18),
     "cfg4-reduced (126 in, 200 out)": (126, [64, 32, 16], [5, 3, 3], 200, 1, 2, 12, 20),
     "wide-hidden-48": (3, [48], [3], 3, 2, 2, 13, 33),
+    # thick inputs that still fold (ceil(3*65/32) = 7 < 9 K-steps): the pack kernel's channel-row tile is 78 KiB (> 64 KiB:
+    # opt-in LDS size) on a 1-degree-wide grid, and 180 KiB (> the CU's LDS: per-element pack path) for 100 channels x 450
+    "folded-65-channels-wide-grid": (65, [16], [3], 1, 1, 2, 9, 298),
+    "folded-100-channels-450-wide": (100, [16], [3], 1, 1, 1, 8, 450),
 }
 
 
@@ -101,7 +105,7 @@ def test_full_size_properties(pkg):
     r = float((outs["bf16"] - outs["f32"]).norm() / outs["f32"].norm())
     rg = float((grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm())
     print(f"  bf16 vs f32 at full size: pred rel-L2 {r:.2e}, grads rel-L2 {rg:.2e}")
-    assert r < 2e-2 and rg < 5e-2
+    assert r < 2e-2 and rg < 2e-2
     assert torch.isfinite(grads["f32"]).all()
 
 

@@ -137,6 +137,37 @@ def test_dataset_device_batch_matches_oracle_preproc(pkg):
         assert torch.equal(Xi, X[1]) and yi.shape == ((90, 144) if levels == 1 else (levels, 90, 144))
 
 
+def test_from_arrays_dataset_on_device_matches_oracle_preproc(pkg):
+    """`E33OMA90D_CRNN.from_arrays` (dataset.py:551-637 on caller-held arrays; page-locked staging, one asynchronous upload):
+    the device batch equals the numpy restatement of the whole chain -- stack, z-score with the training-part statistics,
+    window, cyclic-lon / lat pad (dataset.py:584-634) -- and the slab path writes the same values."""
+    from nasa_niswan_amd.dataset import E33OMA90D_CRNN
+    from nasa_niswan_amd.trainer import FusedTrainer
+    from oracle import preproc_oracle as PO
+    rng = np.random.default_rng(8)
+    n, H, W, T = 64, 90, 144, 6
+    arrs = [(rng.standard_normal((n, H, W)) * s + m).astype(np.float32) for m, s in ((0.2, 6.5), (0.3, 5.3), (0, 6e-5), (2.2, 7.3), (0.2, 2.6), (5.0, 57.0))]
+    ds = E33OMA90D_CRNN.from_arrays(*arrs, period="train", padding=(100, 154), sequence_length=T, device="cuda")
+    assert ds._device_arrays()["u"].is_cuda and len(ds) == 45
+    idx = [0, 17, 44]
+    X, y = ds.device_batch(idx)
+    torch.cuda.synchronize()
+    assert X.shape == (3, T, 5, 100, 154) and y.shape == (3, 90, 144)
+    for b, i in enumerate(idx):
+        ref = PO.preproc_sample(*(a[i:i + T] for a in arrs[:5]), ds.X_mean, ds.X_std, (100, 154), "reference")
+        np.testing.assert_allclose(X[b].cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(y[b].cpu().numpy(), (arrs[5][i + T - 1] - ds.y_mean) / ds.y_std, rtol=1e-6, atol=1e-6)
+    # and it trains: the slab path and the tensor path give the same first-step loss in f32 (same values, same kernels)
+    losses = []
+    for feed in ("slab", "tensor"):
+        torch.manual_seed(0)
+        net = pkg.ConvLSTM(5, [8, 8], [3, 3], 2).cuda()
+        tr = FusedTrainer(net, lr=1e-3, halo=(5, 5))
+        Xb, yb = ds.slab_batch(idx) if feed == "slab" else ds.device_batch(idx)
+        losses.append(float(tr.step(Xb, yb)))
+    assert losses[0] == losses[1], losses
+
+
 @pytest.mark.parametrize("fold", [True, False], ids=["xfold", "plain"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_slab_batch_is_bit_identical_to_preproc_then_pack(pkg, dtype, fold):
@@ -260,7 +291,7 @@ def test_bench_under_torchrun_with_rccl_group(pkg):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--batch", "2", "--force-dist", "--no-cpu-baseline"]
+           "--batch", "2", "--force-dist", "--no-cpu-baseline", "--long-steps", "4"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -268,6 +299,34 @@ def test_bench_under_torchrun_with_rccl_group(pkg):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1" and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    # the collective by itself: timed on the step's stream around dist.all_reduce of the flat bucket
+    assert d["allreduce_ms"] > 0 and d["allreduce_bytes"] == 4 * 945428 and d["bus_bw_GBs"] is None      # one rank: no bus traffic
+    assert d["value_200steps"] > 0 and d["long_window"]["steps"] == 4
+    # kernels priced inside the step by the probe stamps, the warm loop beside them
+    r = d["roofline"]
+    assert r["timing"].startswith("in-step") and r["ms_per_launch"] > 0 and r["ms_per_launch_loop"] > 0
+    ph = d["phases"]["per_step_us"]
+    assert ph["gate0"]["launches"] == 12 and ph["wgrad0"]["launches"] == 1 and 0 < d["phases"]["probe_pair_cost_us"] < 50
+
+
+def test_bench_starts_its_own_ranks(pkg):
+    """`python bench.py --gpus 1 --force-dist` is what the driver runs for N = 1; for N > 1 the same form must start N
+    ranks by itself.  On this one-GPU box: the parent decides from argv, the torchrun child runs the single rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "1", "--force-dist", "--no-cpu-baseline",
+            "--no-kernel-rooflines", "--long-steps", "0", "--master-port", "29579"]
+    args = bench.parse_args(argv)
+    code = ("import sys; sys.path.insert(0, %r); import bench; a = %r; "
+            "raise SystemExit(bench.spawn_ranks(bench.parse_args(a), a))") % (root, argv)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["allreduce_ms"] > 0 and d["roofline"] is None
 
 
 def test_inference_helpers_match_oracle(pkg):

@@ -152,3 +152,36 @@ def test_module_tree_matches_reference_state_dict():
         assert hasattr(cell, attr), attr
     with pytest.raises(AssertionError):
         pkg.ConvLSTM(5, [64, 32], [5, 3, 3], 3)
+
+
+def test_from_arrays_reproduces_the_reference_in_memory_dataset():
+    """f-3 as the survey words it: `E33OMA90D_CRNN` (dataset.py:551-637) on arrays the caller holds.  A 4320-step record
+    (the reference's 90 days x 48) on a tiny grid: split 3023 / 432 / rest, statistics over the first 3023 steps, windows and
+    target lag against the numpy restatement of dataset.py:584-616."""
+    import numpy as np
+    from nasa_niswan_amd.dataset import E33OMA90D_CRNN, reference_split
+    from oracle import preproc_oracle as PO
+    assert reference_split(4320) == (3023, 3455)
+    rng = np.random.default_rng(3)
+    n, H, W, T = 4320, 4, 6, 7
+    arrs = [(rng.standard_normal((n, H, W)) * s + m).astype(np.float32) for m, s in ((0.2, 6.5), (0.3, 5.3), (0, 6e-5), (2.2, 7.3), (0.2, 2.6), (5.0, 57.0))]
+    sizes = {}
+    for period in ("train", "val", "test"):
+        ds = E33OMA90D_CRNN.from_arrays(*arrs, period=period, padding=None, sequence_length=T, device="cpu")
+        Xr, yr, Xm, Xs, ym, ys = PO.inmemory_rnn_dataset(*arrs, period, T)
+        sizes[period] = len(ds)
+        assert len(ds) == len(yr) == len(Xr)
+        np.testing.assert_allclose(ds.X_mean, Xm.reshape(-1), rtol=1e-6)
+        np.testing.assert_allclose(ds.X_std, Xs.reshape(-1), rtol=1e-6)
+        np.testing.assert_allclose(ds.y_mean, ym.reshape(()), rtol=1e-6)
+        np.testing.assert_allclose(ds.y_std, ys.reshape(()), rtol=1e-6)
+        for i in (0, len(ds) // 2, len(ds) - 1):
+            fields, ylast = ds.window(i)
+            raw = np.stack([f[:, 0] if f.ndim == 4 else f for f in fields], axis=1)             # (T, 5, H, W)
+            np.testing.assert_allclose((raw - Xm) / Xs, Xr[i], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose((ylast[0] - ym[0]) / ys[0], yr[i], rtol=1e-5, atol=1e-6)
+    assert sizes == {"train": 3023, "val": 432, "test": 4320 - T + 1 - 3455}
+    with pytest.raises(TypeError, match="from_arrays"):
+        E33OMA90D_CRNN("train", "bcb", (100, 154))
+    with pytest.raises(ValueError, match="prec"):
+        E33OMA90D_CRNN.from_arrays(arrs[0], arrs[1], arrs[2], arrs[3][:, :2], arrs[4], arrs[5], device="cpu")

@@ -2,7 +2,7 @@
 """Phase timeline and in-kernel clock of the gate / dgrad kernel (diagnostic build only).
 
     hipcc ... -DNINT_STAMP -> nasa-niswan_amd/build/libnint_stamp.so   (see tools/build_stamp.sh)
-    NINT_LIB=nasa-niswan_amd/build/libnint_stamp.so python tools/clockprobe.py [--kernel fwd0|dgrad0|fwd1|dgrad1]
+    python tools/clockprobe.py [--kernel fwd0|dgrad0|fwd1|dgrad1] [--lib nasa-niswan_amd/build/libnint_stamp.so]
 
 Every workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz) at entry, after the halo
 fill, after the K loop and at exit (MI355X_MICROARCH.md, DVFS give-back item 6).  Prints the clock the
@@ -25,8 +25,9 @@ def main():
     ap.add_argument("--kernel", default="fwd0")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--lib", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nasa-niswan_amd", "build", "libnint_stamp.so"))
     args = ap.parse_args()
-    lib = pkg.load_library()
+    lib = pkg.load_library(args.lib)          # the -DNINT_STAMP build, by explicit path (tools/build_stamp.sh)
     rd = lib.nint_debug_read_stamps          # AttributeError: not a -DNINT_STAMP build
     rd.restype, rd.argtypes = C.c_int, [C.c_void_p, C.c_int]
     hidden, ks = (64, 32, 16), (5, 3, 3)

@@ -20,15 +20,22 @@ for a, b in zip(starts[:-1], starts[1:]):
     tot_busy += busy; tot_gap += span - busy; ngap += len(gaps)
     big += sorted(gaps, reverse=True)[:3]
 n = len(starts) - 1
-# per-kernel time per step (template arguments kept: they tell the layers apart)
+# per-kernel time per step (template arguments kept: they tell the layers apart).  The FIRST launch of a kernel in a step is
+# kept apart: for the gate kernels it is time step 0, which has no h half of K (half the work of the other launches)
 per = {}
-for e in ev[starts[0]:starts[-1]]:
-    nm = e[2].split("(")[0][:60]
-    t = per.setdefault(nm, [0, 0])
-    t[0] += 1; t[1] += e[1] - e[0]
-for nm, (cnt, ns) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+for a, b in zip(starts[:-1], starts[1:]):
+    seen = set()
+    for e in ev[a:b]:
+        nm = e[2].split("(")[0][:60]
+        t = per.setdefault(nm, [0, 0, 0, 0])
+        t[0] += 1; t[1] += e[1] - e[0]
+        if nm not in seen:
+            seen.add(nm)
+            t[2] += 1; t[3] += e[1] - e[0]
+for nm, (cnt, ns, c1, ns1) in sorted(per.items(), key=lambda kv: -kv[1][1]):
     if ns / n / 1e3 >= 5:
-        print(f"  {nm:60s} {cnt / n:6.1f} launches  {ns / cnt / 1e3:8.1f} us each  {ns / n / 1e3:8.1f} us per step")
+        rest = f"   first launch of the step {ns1 / c1 / 1e3:7.1f} us, the others {(ns - ns1) / (cnt - c1) / 1e3:7.1f} us" if cnt > c1 else ""
+        print(f"  {nm:60s} {cnt / n:6.1f} launches  {ns / cnt / 1e3:8.1f} us each  {ns / n / 1e3:8.1f} us per step{rest}")
 print(f"{n} steps: {tot_busy / n / 1e3:.1f} us busy + {tot_gap / n / 1e3:.1f} us idle per step, {ngap // n} launches per step, mean gap {tot_gap / max(ngap, 1) / 1e3:.2f} us")
 for g in sorted(big, reverse=True)[:8]:
     print(f"  gap {g[0] / 1e3:7.1f} us after {g[1]} -> {g[2]}")

@@ -9,8 +9,6 @@ import sys
 
 import torch
 
-if "--exp" in sys.argv:      # experiment build (python nasa-niswan_amd/build.py --exp): must be chosen before the package loads
-    os.environ["NINT_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nasa-niswan_amd", "libnint_hip_exp.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nasa_niswan_amd as pkg  # noqa: E402
 from nasa_niswan_amd.engine import LayerCfg, SeqEngine  # noqa: E402
@@ -37,12 +35,12 @@ def main():
     ap.add_argument("--H", type=int, default=100)
     ap.add_argument("--W", type=int, default=154)
     ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (data-dependent power / clock check)")
-    ap.add_argument("--exp", action="store_true", help="load the experiment build libnint_hip_exp.so")
-    ap.add_argument("--dbg", type=int, default=0, help="experiment build: tile-configuration selector for every layer")
+    ap.add_argument("--lib", default=None, help="load this build of the library instead of the product one (A/B copies, stamp builds)")
+    ap.add_argument("--wide", type=int, default=-1, help="nint_layer.wide of every layer (-1: the engine's choice)")
     ap.add_argument("--tile-rows", type=int, default=0, help="force 4- or 8-row tiles for the gate / dgrad kernels")
     ap.add_argument("--split", type=int, default=1, help="issue the forward gate kernel as this many launches over image groups")
     args = ap.parse_args()
-    lib = pkg.load_library()
+    lib = pkg.load_library(args.lib) if args.lib else pkg.load_library()
     hidden, ks = (64, 32, 16), (5, 3, 3)
     cfgs, cin = [], args.C
     for ch, k in zip(hidden, ks):
@@ -51,7 +49,9 @@ def main():
     _engine.FORCE_TILE_ROWS = args.tile_rows
     eng = SeqEngine(cfgs, args.dtype, "cuda")
     for ly in eng.layers:
-        ly.tile_rows = args.tile_rows | (args.dbg << 8)
+        ly.tile_rows = args.tile_rows
+        if args.wide >= 0:
+            ly.wide = args.wide
     B, T, H, W = args.batch, args.T, args.H, args.W
     ws = eng.acquire(B, T, H, W, True, False)
     ws_w = [torch.randn(4 * c.Ch, c.Cx + c.Ch, c.k, c.k, device="cuda") * (0.0 if args.zeros else 0.05) for c in cfgs]
