@@ -771,6 +771,11 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
   a.tile_rows = ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
+  if (ly->wide < 0 || ly->wide > 2) return NINT_E_ARG;
+  if (dtype == NINT_BF16 && ly->wide != 1) {     // wide layers with enough tiles: the 8-wave LDS-weight kernel (conv_wide.hip)
+    const int rc = nint_internal_conv_wide_lstm(a, N, ly->wide == 2, stream);
+    if (rc != NINT_E_SHAPE) return rc;
+  }
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st);
 }

@@ -175,6 +175,9 @@ struct WgJob {           // one layer's weight / bias gradient
 };
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
                                    size_t partial_bytes, int n_cu, void* stream, Probe* probe = nullptr);
+// conv_wide.hip: the persistent 8-wave gate kernel with the weight tiles staged once per workgroup in LDS (bf16, wide layers).
+// force = nint_layer.wide == 2.  NINT_E_SHAPE = not served: the caller takes conv_igemm.hip's 4-wave kernel.
+int nint_internal_conv_wide_lstm(const ConvArgs& a, int N, int force, void* stream);
 struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
   // optional: the layer below's pointwise backward of THIS time step, run on the x columns (the layer's dh buffer is only read)
