@@ -67,7 +67,8 @@ typedef struct nint_layer {
   int32_t wide;           /* gate / dgrad kernel family: 0 = chosen per launch shape; 1 = always the 4-wave kernels whose waves
                            * stream their own weight fragments from L2 (csrc/conv_igemm.hip); 2 = the 8-wave kernel that stages
                            * each K-step's weight tile ONCE per workgroup in LDS (csrc/conv_wide.hip) wherever it is
-                           * instantiated (bf16, 256 gate columns).  Same arithmetic, same summation order per output. */
+                           * instantiated (bf16, gate columns a multiple of 128, k = 3 or 5); 3 / 4 = that, with its 256- / 512-pixel
+                           * tiles forced (tests).  Same arithmetic, same summation order per output. */
   const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */
   const void* Wd;         /* dgrad weights (transposed + flipped), ET */
   const float* bias_p;    /* bias permuted to gate-stash column order [4*Ch16] */

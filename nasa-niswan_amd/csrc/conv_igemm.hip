@@ -717,13 +717,27 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
   const int ksteps = a.nchunk0 * a.k * a.kx0 + a.nchunk1 * a.taps;
   // (measured with the leftover strip merged, B = 8, 100x154: dgrad layer 0 -- 200 steps, 4 column tiles -- 94.7 us with
   // 8-row tiles against 104.0; dgrad layer 1 -- 36 steps -- 40.2 against 41.5; the 18-27-step launches prefer 4 rows)
-  const bool mt4 = a.tile_rows ? a.tile_rows == 4
-                               : (EPI != EPI_LSTM ? ksteps <= 32 : (ksteps <= 48 || ntiles <= 4));
+  bool mt4 = a.tile_rows ? a.tile_rows == 4
+                         : (EPI != EPI_LSTM ? ksteps <= 32 : (ksteps <= 48 || ntiles <= 4));
+  int n_cu = 256;
+  { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
+  // few images (B = 1 or 2 per GPU): 8-row tiles would leave CUs without a workgroup; 4-row tiles double the count
+  if (!a.tile_rows && 2 * N * nint_cdiv(a.W, 16) * nint_cdiv(a.H, 8) < 3 * n_cu) mt4 = true;
   if constexpr (EPI == EPI_LSTM) {
     if (ntiles % 4) return NINT_E_SHAPE;
     const int cbs = ntiles / 4;
-    if (cbs % 4 == 0) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, cbs / 4, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, cbs / 4, st);
-    if (cbs % 2 == 0) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st);
+    // Small batches (the strong-scaling shape: B = 1 per GPU is 125 8-row tiles for 256 CUs): when the pixel tiles alone
+    // leave CUs empty, the gate columns are split over more workgroups (column groups on blockIdx.y: the waves that no
+    // longer have columns of their own slice K instead) -- each then re-stages the halo tile, which an idle CU does for free.
+#ifndef NINT_SPLIT_NUM
+#define NINT_SPLIT_NUM 3        // split while workgroups < NINT_SPLIT_NUM / 2 per CU
+#endif
+    const int ptiles = N * nint_cdiv(a.W, 16) * nint_cdiv(a.H, mt4 ? 4 : 8);
+    // (an explicit nint_layer.tile_rows pins the launch shape: no split)
+    const bool few4 = !a.tile_rows && 2 * ptiles * (cbs / 4 > 0 ? cbs / 4 : 1) < NINT_SPLIT_NUM * n_cu;       // with 4 column blocks per workgroup
+    const bool few2 = !a.tile_rows && 2 * ptiles * (cbs / 2 > 0 ? cbs / 2 : 1) < NINT_SPLIT_NUM * n_cu;       // with 2
+    if (cbs % 4 == 0 && !few4) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, cbs / 4, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, cbs / 4, st);
+    if (cbs % 2 == 0 && !few2) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st);
     return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st);
   } else {
     // (WN, NTW) with WN*NTW dividing the tile count, widest first; leftover waves split K
@@ -771,9 +785,9 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
   a.tile_rows = ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
-  if (ly->wide < 0 || ly->wide > 2) return NINT_E_ARG;
-  if (dtype == NINT_BF16 && ly->wide != 1) {     // wide layers with enough tiles: the 8-wave LDS-weight kernel (conv_wide.hip)
-    const int rc = nint_internal_conv_wide_lstm(a, N, ly->wide == 2, stream);
+  if (ly->wide < 0 || ly->wide > 12 || (ly->wide & 7) > 4) return NINT_E_ARG;
+  if (dtype == NINT_BF16 && (ly->wide & 7) != 1) {     // wide layers with enough tiles: the 8-wave LDS-weight kernel (conv_wide.hip)
+    const int rc = nint_internal_conv_wide_lstm(a, N, ly->wide, stream);
     if (rc != NINT_E_SHAPE) return rc;
   }
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st)

@@ -36,6 +36,7 @@
 // hipcc does not know about the inline-asm DMA (it counts neither their vmcnt nor their LDS writes); its own counted waits
 // for the epilogue's loads stay correct because vmcnt retires in order (extra older / younger operations only make a
 // compiler-computed wait more conservative).
+#include <type_traits>
 #include "nint_common.h"
 
 struct WideArgs {
@@ -50,18 +51,51 @@ struct WideArgs {
   int R[2], Cb[2], HWt[2], NHP[2];
   unsigned magic_hwt[2];
   int tiles_x[2], tiles_y0, tiles_img, ntiles;
+  int ny, nunits;                              // column-group sets (of 64*CG gate columns) per pixel tile; units = ntiles * ny
   int nhpp;                                    // pixels per g-plane of a chunk slot (>= NHP of both classes, multiple of 16)
   unsigned magic_nhpp;
   int npc, pps;                                // 1-KiB pieces per chunk; pieces per wave per K-step while a chunk is being fetched
   int spt;                                     // K-steps per tile
+  int rot;                                     // 1: every workgroup starts the taps of a chunk at its own tap (blockIdx.x % taps)
   const float* bias; const float* c_prev; float* c_out; char* h_out; char* gates_out;
   int Chp, Ch16;
 };
 
-struct WTile { int img, y0, x0, cls; };
+struct WTile { int img, y0, x0, cls, ch; };
 
-__device__ __forceinline__ WTile wide_tile(const WideArgs& a, int id) {
+#ifdef NINT_STAMP
+// Diagnostic build only (tools/wideprobe.py): per-wave cycle totals of the K loop's segments.  The values go to a buffer of
+// their own that no kernel reads; the shipped library is built without NINT_STAMP.
+#define WIDE_STAMP_WGS 512
+__device__ unsigned long long g_wide_stamp[WIDE_STAMP_WGS * 8 * 16];
+extern "C" int nint_debug_read_wide_stamps(unsigned long long* host, int n_wgs) {
+  if (!host || n_wgs <= 0 || n_wgs > WIDE_STAMP_WGS) return NINT_E_ARG;
+  NINT_CHECK_HIP(hipDeviceSynchronize());
+  NINT_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wide_stamp), (size_t)n_wgs * 8 * 16 * sizeof(unsigned long long)));
+  return NINT_OK;
+}
+#if NINT_STAMP >= 2      // full: every segment of every K-step (the stamps themselves cost ~130 cycles per pair and drain lgkmcnt)
+#define WSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#define WACC(slot, a_, b_) st_acc[slot] += (b_) - (a_);
+#else                    // light: whole-run totals only (prologue, epilogues; the K loop is undisturbed)
+#define WSTAMP(var)
+#define WACC(slot, a_, b_)
+#endif
+#define WSTAMP1(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#define WACC1(slot, a_, b_) st_acc[slot] += (b_) - (a_);
+#else
+#define WSTAMP1(var)
+#define WACC1(slot, a_, b_)
+#define WSTAMP(var)
+#define WACC(slot, a_, b_)
+#endif
+
+// unit u = (pixel tile u / ny, column-group set u % ny): the sets of one pixel tile are consecutive units, so the workgroup
+// (or its XCD neighbours) that runs the next set finds the tile's halo pixels in L2
+__device__ __forceinline__ WTile wide_tile(const WideArgs& a, int u) {
   WTile t;
+  const int id = u / a.ny;
+  t.ch = u - id * a.ny;
   t.img = id / a.tiles_img;
   int r = id - t.img * a.tiles_img;
   const int n0 = a.tiles_x[0] * a.tiles_y0;
@@ -75,11 +109,66 @@ __device__ __forceinline__ WTile wide_tile(const WideArgs& a, int id) {
   return t;
 }
 
-// one 1-KiB LDS-DMA piece: lane l copies 16 bytes from gsrc (per lane) to lds_dst + 16*l (wave-uniform base in M0)
+// One 1-KiB LDS-DMA piece: lane l copies 16 bytes from gsrc (per lane) to lds_dst + 16*l (wave-uniform base in M0).
+// M0 is written and NOT restored: nothing else in this translation unit's kernels uses M0 (gfx950 LDS instructions do not;
+// tools/regs.py --m0 audits the ISA), and a restore right behind the DMA would be a second M0 write that has to wait for
+// the DMA to have read it.
 __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#ifdef WIDE_ABL_FIXEDM0      // timing experiment (wrong results): no M0 write in front of the DMA
+  asm volatile("global_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
+}
+// two consecutive pieces (global +1024, LDS +1024: the instruction offset applies to both addresses) behind ONE M0 write
+__device__ __forceinline__ void glds16x2(const char* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+               : : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// A 16-byte load the compiler does not count (so that it cannot drain the queue with vmcnt(0) at the next control-flow join):
+// the destination is valid only behind wait_vm_regs<N>(), which names it "+v" (cdna_hip_programming.md 5.7 item 1, form (ii)).
+__device__ __forceinline__ void gload16_asm(u32x4_t& dst, const char* src) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm_regs(u32x4_t& r0) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm_regs(u32x4_t& r0, u32x4_t& r1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N) : "memory");
+}
+// the same with a wave-uniform run-time count (0 .. 10): a scalar branch to the matching immediate
+#define NINT_VMCASE(K, ...) case K: asm volatile("s_waitcnt vmcnt(" #K ")" : __VA_ARGS__ : : "memory"); break;
+__device__ __forceinline__ void wait_vm_regs_rt(int n, u32x4_t& r0) {
+  switch (n) {
+    NINT_VMCASE(1, "+v"(r0)) NINT_VMCASE(2, "+v"(r0)) NINT_VMCASE(3, "+v"(r0)) NINT_VMCASE(4, "+v"(r0)) NINT_VMCASE(5, "+v"(r0))
+    NINT_VMCASE(6, "+v"(r0)) NINT_VMCASE(7, "+v"(r0)) NINT_VMCASE(8, "+v"(r0)) NINT_VMCASE(9, "+v"(r0)) NINT_VMCASE(10, "+v"(r0))
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0) : : "memory"); break;
+  }
+}
+__device__ __forceinline__ void wait_vm_regs_rt(int n, u32x4_t& r0, u32x4_t& r1) {
+  switch (n) {
+    NINT_VMCASE(1, "+v"(r0), "+v"(r1)) NINT_VMCASE(2, "+v"(r0), "+v"(r1)) NINT_VMCASE(3, "+v"(r0), "+v"(r1)) NINT_VMCASE(4, "+v"(r0), "+v"(r1))
+    NINT_VMCASE(5, "+v"(r0), "+v"(r1)) NINT_VMCASE(6, "+v"(r0), "+v"(r1)) NINT_VMCASE(7, "+v"(r0), "+v"(r1)) NINT_VMCASE(8, "+v"(r0), "+v"(r1))
+    NINT_VMCASE(9, "+v"(r0), "+v"(r1)) NINT_VMCASE(10, "+v"(r0), "+v"(r1))
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1) : : "memory"); break;
+  }
+}
+#undef NINT_VMCASE
+__device__ __forceinline__ void wait_vm_rt(int n) {       // wave-uniform run-time count: a scalar branch to the matching immediate
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
 }
 template <int N> __device__ __forceinline__ void wait_vm() {
   if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -87,7 +176,11 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else static_assert(N < 0, "add the immediate");
 }
@@ -97,13 +190,20 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int PS, int D, int R, int KS>
+template <int PS, int D, int R, int KS, bool WREG>
 __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
-  constexpr int CG = 8 / PS, RPW = 16 / PS, NTW = 4;
+  constexpr int CG = 8 / PS, RPW = 8, NTW = 4;       // 8 row tiles x 4 column tiles per wave: 128 accumulator registers
   constexpr int k = KS, taps = KS * KS, p = KS / 2;
   constexpr int WT_BYTES = 4 * CG * 1024;            // weight tile of one K-step
   constexpr int PPWB = CG >= 2 ? CG / 2 : 1;         // weight pieces per wave per K-step (CG = 1: waves 0-3 only)
-  static_assert(D >= 4, "group 1 waits D-3 steps ahead");
+  // WREG: the weight tile goes global -> registers -> LDS (plain loads two K-steps ahead into two register sets, ds_write one
+  // step ahead into a 2-slot ring) instead of by LDS-DMA into a D-slot ring.  Measured (tools/wideprobe.py): an LDS-DMA piece
+  // costs its issuing wave ~190 cycles here -- 17 pieces per K-step and CU made P1 570 cycles long against the 512 of the
+  // other group's MFMAs -- while the 4-wave kernel shows that plain 1-KiB fragment loads at twice this rate issue freely.
+  // WREG ring: THREE slots.  The fragment reads of P1 stay in flight across the barrier (they are consumed by the MFMAs of P2),
+  // so when group 0 writes step s+1 in P1(s), group 1's reads of step s-1 may still be pending: with two slots that is the
+  // slot being written (a rare wrong tile, found as a NaN after a few hundred launches); with three it is another one.
+  static_assert(WREG ? D == 3 : D >= 4, "DMA ring: group 1 waits D-3 steps ahead; register staging: three slots");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,26 +220,101 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
   {
     const int G = gridDim.x, b = blockIdx.x, x = b % 8, i = b / 8;
     const int nx = G / 8 + (x < G % 8 ? 1 : 0);
-    const int q8 = a.ntiles / 8, r8 = a.ntiles % 8;
+    const int q8 = a.nunits / 8, r8 = a.nunits % 8;
     const int lo = x * q8 + (x < r8 ? x : r8), sz = q8 + (x < r8 ? 1 : 0);
     t_first = lo + i; t_stride = nx;
     t_cnt = i < sz ? (sz - i + nx - 1) / nx : 0;
   }
   if (t_cnt == 0) return;
+#ifdef NINT_STAMP
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int S = t_cnt * spt;                          // K-steps of this workgroup's whole run
-  const int nt0 = blockIdx.y * 4 * CG + cg * 4;       // first n-tile of this wave
+  int nt0;                                            // first n-tile of this wave in the unit being computed
 
   // ---- DMA issue ------------------------------------------------------------------------------------------------
-  // weights: piece j of step ws comes from Bp + ((ws * NTt + blockIdx.y * 4 * CG + j) << 10), lane-linear on both sides
-  const char* Bwg = a.Bp + (size_t)blockIdx.y * WT_BYTES + lane * 16;
-  const size_t bstep = (size_t)a.NTt * 1024;
-  auto issue_weights = [&](int ws, int slot) __attribute__((always_inline)) {
-    if (CG == 1 && wave >= 4) return;
-#pragma unroll
-    for (int i = 0; i < PPWB; ++i) {
-      const int j = wave * PPWB + i;
-      glds16(Bwg + (size_t)ws * bstep + j * 1024, wring + slot * WT_BYTES + j * 1024);
+  // All per-step bookkeeping is INCREMENTAL scalar state (no division, no multiplication, no kernel-argument reload in the
+  // K loop): the whole of P1 must fit under the 512 cycles of the other wave group's MFMAs.
+  // weights: piece j of K-step ws of column-group set ch comes from Bp + ((ws * NTt + ch * 4 * CG + j) << 10), lane-linear on both sides
+  const char* Bw_lane_reg = a.Bp + (size_t)(wave * PPWB) * 1024 + lane * 16;   // (WREG) this wave's first piece of step 0, set 0
+  const unsigned bstep = (unsigned)a.NTt * 1024;
+  const int ny = a.ny;
+  int w_ch = t_first % ny;                            // column-group set of the unit whose weights are being fetched
+  const int w_chstep = t_stride % ny;                 // ... and how it moves from one of this workgroup's units to the next
+  // K order: chunk by chunk, and inside a chunk the k*k taps CYCLICALLY from this workgroup's own first tap t0.  In plain
+  // order all 256 persistent workgroups walk the packed weights in lockstep, i.e. every CU of an XCD asks its L2 for the
+  // same 16 KiB at the same moment, step after step; rotated, the requests of a moment spread over k*k weight tiles.
+  // (f32 accumulation order, hence the last bits, then depend on the workgroup: deterministic for a given launch shape.)
+  const int t0 = a.rot ? (int)(blockIdx.x % taps) : 0;
+  const int ty0 = t0 / k, tx0 = t0 - ty0 * k;
+  unsigned w_off = (unsigned)w_ch * WT_BYTES + (unsigned)t0 * bstep;   // byte offset of the next step to issue inside the packed weights
+  int w_left = S;                                     // steps not yet issued
+  int w_ws = 0;                                       // ... its index inside its unit
+  int w_tapi = t0, w_cnt = 0;                         // ... its tap, and how many steps of its chunk period have been issued
+  // DMA roles (DMA ring): vmcnt retires in order, so a wave that has issued a long-latency halo piece (HBM / MALL) cannot
+  // confirm a younger weight piece before it -- measured: the ~1.2 halo pieces per K-step and CU cost as much K-loop time
+  // as the 16 weight pieces.  So the halo pieces are issued by waves 3 and 7 (one per group) ALONE, which wait for them once
+  // per chunk period, and the weight pieces by the other six waves, whose counted waits then only ever see L2-latency pieces.
+#ifdef WIDE_ROLE_SPLIT     // experiment: halo pieces by waves 3 / 7 alone, weight pieces by the other six (measured slower: 2586 vs ~1950 cycles per K-step)
+  const bool chunk_wave = !WREG && (wave & 3) == 3;
+  const int wi = wave - (wave >> 2);                  // 0..5 among the weight issuers (waves 0,1,2,4,5,6)
+  constexpr int NPW = 4 * CG, WBASE = NPW / 6, WREM = NPW % 6;
+  const int w_cnt_pieces = WREG ? PPWB : (chunk_wave ? 0 : WBASE + (wi < WREM ? 1 : 0));       // weight pieces this wave issues per K-step
+  const int w_first = WREG ? wave * PPWB : wi * WBASE + (wi < WREM ? wi : WREM);
+#else
+  constexpr bool chunk_wave = false;
+  const int w_cnt_pieces = (CG == 1 && wave >= 4) ? 0 : PPWB;
+  const int w_first = wave * PPWB;
+#endif
+  unsigned w_lds = wring + (unsigned)w_first * 1024;  // LDS address of this wave's first piece in the next ring slot
+  int w_slot = 0;
+  u32x4_t wr[2][PPWB];                                // WREG: the two register sets (K-steps of equal parity share one)
+  auto advance_weights = [&]() __attribute__((always_inline)) {
+    --w_left;
+    w_off += bstep; ++w_ws; ++w_tapi; ++w_cnt;
+    if (w_tapi == taps) { w_tapi = 0; w_off -= taps * bstep; }        // tap k*k-1 -> tap 0 of the same chunk
+    if (w_cnt == taps) { w_cnt = 0; w_off += taps * bstep; }          // period over (the tap is back at t0): next chunk
+    if (w_ws == spt) {                                // next unit of this workgroup: (u + t_stride) % ny
+      w_ws = 0;
+      w_ch += w_chstep;
+      if (w_ch >= ny) w_ch -= ny;
+      w_off = (unsigned)w_ch * WT_BYTES + (unsigned)t0 * bstep;
     }
+  };
+  auto load_weights = [&](auto par) __attribute__((always_inline)) {          // next step's pieces -> register set `par`
+    if (!(CG == 1 && wave >= 4)) {
+#pragma unroll
+      for (int i = 0; i < PPWB; ++i) gload16_asm(wr[decltype(par)::value][i], Bw_lane_reg + w_off + i * 1024);
+    }
+    advance_weights();
+  };
+  // register set `par` -> ring slot.  younger = the vector-memory operations this wave has issued SINCE the set's loads (the
+  // other set's loads, DMA pieces): exactly those may still be in flight (vmcnt retires in order).  An over-count would let the
+  // set's own loads be in flight at the ds_write -- it was one, at the end of a run, where no further loads follow: a rare wrong
+  // column group in the last K-step --; an under-count only waits longer (compiler-issued loads / stores are not counted).
+  auto store_weights = [&](auto par, int slot, int younger) __attribute__((always_inline)) {
+    if (!(CG == 1 && wave >= 4)) {
+      if constexpr (PPWB == 2) wait_vm_regs_rt(younger, wr[decltype(par)::value][0], wr[decltype(par)::value][1]);
+      else wait_vm_regs_rt(younger, wr[decltype(par)::value][0]);
+      char* dst = smem + R * chunk_bytes + slot * WT_BYTES + (wave * PPWB) * 1024 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < PPWB; ++i) *(u32x4_t*)(dst + i * 1024) = wr[decltype(par)::value][i];
+    }
+  };
+  auto issue_weights = [&]() __attribute__((always_inline)) {
+    const char* src = a.Bp + lane * 16 + (size_t)w_first * 1024 + w_off;
+#ifdef WIDE_ROLE_SPLIT
+    for (int i = 0; i < w_cnt_pieces; ++i) glds16(src + i * 1024, w_lds + i * 1024);
+#else
+    if (w_cnt_pieces) {
+      if constexpr (PPWB == 2) glds16x2(src, w_lds);
+      else glds16(src, w_lds);
+    }
+#endif
+    advance_weights();
+    w_lds += WT_BYTES; ++w_slot;
+    if (w_slot == D) { w_slot = 0; w_lds -= D * WT_BYTES; }
   };
   // halo chunk: piece q = 64 consecutive 16-byte units of the slot image [g][halo pixel]; unit u -> (g, halo pixel) ->
   // source address.  Pad units (hp >= NHP) and pixels beyond the slab (tiles that overhang the slack of the halo slab;
@@ -147,32 +322,37 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
   // The chunk being fetched is described by scalars that change once per chunk (fetch descriptor): first byte of the
   // tile's first halo pixel in that chunk, the source's pixel stride, the tile class and the slab's remaining extent.
   const char* f_base; int f_pixs, f_nhp, f_hwt, f_hymax, f_hxmax; unsigned f_magic;
-  auto issue_chunk_piece = [&](int slot, int q) __attribute__((always_inline)) {
+  unsigned f_lds = lds0;                              // LDS address of the slot being filled
+  int f_slot = 0;
+  const int nhpp = a.nhpp, Wh = a.Wh, npc = a.npc, pps = a.pps;
+  const unsigned magic_nhpp = a.magic_nhpp;
+  auto issue_chunk_piece = [&](int q) __attribute__((always_inline)) {
     const int u = q * 64 + lane;
-    const int g = (int)__umulhi((unsigned)u, a.magic_nhpp);
-    int hp = u - g * a.nhpp;
+    const int g = (int)__umulhi((unsigned)u, magic_nhpp);
+    int hp = u - g * nhpp;
     hp = hp < f_nhp ? hp : 0;
     const int hy = (int)__umulhi((unsigned)hp, f_magic);
     const int hx = hp - hy * f_hwt;
     const bool inside = hy < f_hymax && hx < f_hxmax;
-    const int off = inside ? (hy * a.Wh + hx) * f_pixs : 0;
-    glds16(f_base + off + g * 16, lds0 + slot * chunk_bytes + q * 1024);
+    const int off = inside ? (hy * Wh + hx) * f_pixs : 0;
+    glds16(f_base + off + g * 16, f_lds + q * 1024);
   };
 
-  // chunk-fetch cursor: global chunk number d_gc (tile d_j, chunk d_c of it)
-  int d_gc = 0, d_c = 0, d_j = 0;
+  // chunk-fetch cursor: tile d_j, chunk d_c of it
+  int d_c = 0, d_j = 0;
   WTile d_tile = wide_tile(a, t_first);
   auto set_fetch = [&]() __attribute__((always_inline)) {
     const int ay0 = d_tile.y0 + a.P - p, ax0 = d_tile.x0 + a.P - p;
-    const long pix = (long)ay0 * a.Wh + ax0;
+    const long pix = (long)ay0 * Wh + ax0;
     if (d_c < a.nchunk0) { f_pixs = a.pix_stride0; f_base = a.src0 + (long)d_tile.img * a.img_stride0 + pix * a.pix_stride0 + d_c * 64; }
     else { f_pixs = a.pix_stride1; f_base = a.src1 + (long)d_tile.img * a.img_stride1 + pix * a.pix_stride1 + (d_c - a.nchunk0) * 64; }
     f_nhp = a.NHP[d_tile.cls]; f_hwt = a.HWt[d_tile.cls]; f_magic = a.magic_hwt[d_tile.cls];
-    f_hymax = a.Hh - ay0; f_hxmax = a.Wh - ax0;
+    f_hymax = a.Hh - ay0; f_hxmax = Wh - ax0;
   };
   set_fetch();
   auto advance_chunk_cursor = [&]() __attribute__((always_inline)) {
-    ++d_gc;
+    f_lds += chunk_bytes; ++f_slot;
+    if (f_slot == R) { f_slot = 0; f_lds = lds0; }
     if (++d_c == nchunks) {
       d_c = 0; ++d_j;
       if (d_j < t_cnt) d_tile = wide_tile(a, t_first + d_j * t_stride);
@@ -182,13 +362,20 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
 
   // ---- prologue: chunks 0 .. R-2 whole, weights of steps 0 .. D-2; the only full drain of the run
   for (int r = 0; r < R - 1 && d_j < t_cnt; ++r) {
-    for (int q = wave; q < a.npc; q += 8) issue_chunk_piece(d_gc % R, q);
+    for (int q = wave; q < npc; q += 8) issue_chunk_piece(q);       // (the prologue: all eight waves, one drain)
     advance_chunk_cursor();
   }
-  int w_s = 0, w_ws = 0;                              // next weight step to issue: global index, index inside its tile
-  for (; w_s < D - 1 && w_s < S; ++w_s) {
-    issue_weights(w_ws, w_s % D);
-    if (++w_ws == spt) w_ws = 0;
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1_;
+  if constexpr (WREG) {
+    // step 0 -> slot 0 now; step 1 -> set 1 (written in P1(0)); step 2 -> set 0 (written in P1(1))
+    load_weights(P0{});
+    store_weights(P0{}, 0, 0);
+    if (w_left > 0) load_weights(P1_{});
+    if (w_left > 0) load_weights(P0{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+    for (int i = 0; i < D - 1 && w_left > 0; ++i) issue_weights();
   }
   wait_vm<0>();
   wg_barrier();
@@ -204,47 +391,102 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
       for (int i = 0; i < RPW; ++i) acc[i][j] = b0;
     }
   };
+  WTile ct = wide_tile(a, t_first);                   // the unit being computed
+  nt0 = ct.ch * 4 * CG + cg * 4;
   init_acc();
-  WTile ct = wide_tile(a, t_first);                   // the tile being computed
   int c_j = 0, c_ws = 0;                              // its number, K-step inside it
-  int c_gc = 0, c_c = 0, c_tap = 0, tyy = 0, txx = 0; // chunk (global number, index in tile), tap inside the chunk
+  int c_tap = 0, tyy = ty0, txx = tx0;                // step inside the chunk period; the tap it computes
+  int a_soff = 0, a_slot = 0;                         // byte offset of (chunk slot, tap) inside the A ring
+  int b_soff = R * chunk_bytes, b_slot = 0;           // byte offset of this step's weight slot
   const int a_lane_off = (lane >> 4) * plane + (lane & 15) * 16;
   const unsigned blane = (unsigned)(cg * 4 * 1024 + lane * 16);
-  int rowoff[RPW], Rc, HWtc;
-  auto set_rowoff = [&]() __attribute__((always_inline)) {
-    Rc = a.R[ct.cls]; HWtc = a.HWt[ct.cls];
-    const int nrt = Rc * a.Cb[ct.cls];                // row tiles the class really has (narrow grids: fewer than 16)
+  // row tile i of this wave is tile row tile rt = ps*RPW + i at (rt & (Rc-1), 16 * (rt >> lgR)) -- tile heights are powers of two
+  int arow[RPW], lgR, Rm, HWtc, d_rowwrap, nrt;
+  auto set_tile = [&]() __attribute__((always_inline)) {
+    const int Rc = a.R[ct.cls];
+    lgR = 31 - __builtin_clz(Rc); Rm = Rc - 1; HWtc = a.HWt[ct.cls];
+    d_rowwrap = (HWtc - k) * 16;                      // tap (ty, k-1) -> (ty+1, 0), on top of the +16 of every step
+    nrt = Rc * a.Cb[ct.cls];                          // row tiles the class really has (tiles narrower than TRT / R blocks: fewer)
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int rt = ps * RPW + i;
-      rowoff[i] = rt < nrt ? ((rt % Rc) * HWtc + 16 * (rt / Rc)) * 16 : 0;   // (idle row tiles read row tile 0; their pixels lie beyond W: never stored)
+      // (idle row tiles read row tile 0 and store nothing)
+      arow[i] = a_lane_off + (rt < nrt ? ((rt & Rm) * HWtc + 16 * (rt >> lgR)) * 16 : 0);
     }
   };
-  set_rowoff();
+  set_tile();
+  a_soff = (ty0 * HWtc + tx0) * 16;
   f32x4_t cpv[RPW];
 
-  for (int s = 0; s < S; ++s) {
+  WSTAMP1(st_loop0)
+  WACC1(6, st_t0, st_loop0)
+  int s = 0;
+  int vm_np2 = 0, vm_np1 = 0, vm_nl1 = 0;             // WREG: DMA pieces / weight loads this wave issued two steps / one step ago
+  // one K-step; `par` = s & 1 as a type (WREG: it names the register set / ring slot of the step, statically)
+  auto step = [&](auto par) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par)::value;
+    typedef std::integral_constant<int, 1 - PAR> Other;
+    WSTAMP(st_a)
     // ============================== P1(s): DMA issue, fragment reads ==============================
-    // pieces of chunk c_gc + R - 1 (cursor d_*) during the first steps of this chunk period, ahead of the weights
-    if (d_j < t_cnt) {
-      for (int e = 0; e < a.pps; ++e) {
-        const int q = wave + 8 * (c_tap * a.pps + e);
-        if (q < a.npc) issue_chunk_piece(d_gc % R, q);
+    // pieces of the chunk R-1 periods ahead (fetch cursor) during the first steps of this chunk period, ahead of the weights
+    auto issue_dma = [&]() __attribute__((always_inline)) {
+      int nl0 = 0, np0 = 0;                          // loads / DMA pieces this wave issues in this step
+      if constexpr (WREG) {
+        // weights of step s+1 (loaded two steps ago into the other register set) -> the next ring slot: its last readers
+        // (group 1, P1(s-2)) are two barriers behind; then that set takes step s+3.  Issued since those loads: the pieces of
+        // that step, and the loads and pieces of the step in between.
+        if (s + 1 < S) store_weights(Other{}, b_slot == D - 1 ? 0 : b_slot + 1, vm_np2 + vm_nl1 + vm_np1);
+        if (w_left > 0) { load_weights(Other{}); nl0 = (CG == 1 && wave >= 4) ? 0 : PPWB; }
       }
-    }
-    if (w_s < S) {
-      issue_weights(w_ws, w_s % D);
-      ++w_s;
-      if (++w_ws == spt) w_ws = 0;
-    }
+#ifndef WIDE_ABL_NOCHUNK
+      if (d_j < t_cnt) {
+        if constexpr (WREG) {
+          for (int e = 0; e < pps; ++e) {
+            const int q = wave + 8 * (c_tap * pps + e);
+            if (q < npc) { issue_chunk_piece(q); ++np0; }
+          }
+        }
+#ifdef WIDE_ROLE_SPLIT
+        else if (chunk_wave) {                       // waves 3 / 7 take the even / odd pieces, pps of them per step
+          for (int e = 0; e < pps; ++e) {
+            const int q = 2 * (c_tap * pps + e) + (wave >> 2);
+            if (q < npc) issue_chunk_piece(q);
+          }
+        }
+#else
+        else {
+          for (int e = 0; e < pps; ++e) {
+            const int q = wave + 8 * (c_tap * pps + e);
+            if (q < npc) issue_chunk_piece(q);
+          }
+        }
+#endif
+      }
+#endif
+      if constexpr (!WREG) {
+#ifdef WIDE_ABL_NOWEIGHTS
+        if (w_left > 0) { --w_left; }
+#else
+        if (w_left > 0) issue_weights();
+#endif
+      }
+      vm_np2 = vm_np1; vm_np1 = np0; vm_nl1 = nl0;
+    };
+#if !defined(WIDE_DMA_IN_P2) && !defined(WIDE_ABL_NODMA)
+    issue_dma();
+#endif
+    WSTAMP(st_a1)
+    WACC(8, st_a, st_a1)
     u32x4_t bq[NTW], ax[RPW];
+#ifdef WIDE_ABL_NOREADS
+    if (s == 0)
+#endif
     {
-      const char* Bs = smem + R * chunk_bytes + (s % D) * WT_BYTES + blane;
+      const char* Bs = smem + b_soff + blane;
 #pragma unroll
       for (int j = 0; j < NTW; ++j) bq[j] = *(const u32x4_t*)(Bs + j * 1024);
-      const char* As = smem + (c_gc % R) * chunk_bytes + (tyy * HWtc + txx) * 16 + a_lane_off;
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) ax[i] = *(const u32x4_t*)(As + rowoff[i]);
+      for (int i = 0; i < RPW; ++i) ax[i] = *(const u32x4_t*)(smem + (a_soff + arow[i]));
     }
     const bool last = c_ws + 1 == spt;                // last K-step of the tile
     if (last) {                                       // c_{t-1} of the tile's rows, one K-step ahead of the epilogue
@@ -252,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
           const int rt = ps * RPW + i;
-          const int y = ct.y0 + rt % Rc, xq = ct.x0 + 16 * (rt / Rc) + (lane & 15);
+          const int y = ct.y0 + (rt & Rm), xq = ct.x0 + 16 * (rt >> lgR) + (lane & 15);
           const bool in = y < a.H && xq < a.W;
           const float* crow = a.c_prev + ((size_t)ct.img * a.H + (y < a.H ? y : 0)) * a.W * a.Chp;     // wave-uniform row base
           cpv[i] = *(const f32x4_t*)(crow + (unsigned)((in ? xq : 0) * a.Chp + (nt0 / 4) * 16 + 4 * (lane >> 4)));
@@ -262,28 +504,70 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
         for (int i = 0; i < RPW; ++i) cpv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       }
     }
+    WSTAMP(st_a2)
+    WACC(9, st_a1, st_a2)
+    // this wave's ds_write of step s+1 is in LDS before the barrier: the RPW + NTW fragment reads behind it may stay in flight
+    // (LDS operations complete in order; SMEM loads, which share the counter, can only complete earlier)
+    if constexpr (WREG) asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(RPW + NTW) : "memory");
+    WSTAMP(st_b)
     wg_barrier();
+    WSTAMP(st_c)
     // ============================== P2(s): MFMAs, counted wait ==============================
+    constexpr int MG = RPW >= 4 ? 4 : RPW;            // row groups
+    constexpr int RG = RPW / MG;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < RPW; ++i)
+    for (int gq = 0; gq < MG; ++gq) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<NINT_BF16>(bq[j], ax[i], acc[i][j]);   // swapped: D[channel][pixel]
+      for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[gq * RG + r][j] = mma_step<NINT_BF16>(bq[j], ax[gq * RG + r], acc[gq * RG + r][j]);   // swapped: D[channel][pixel]
+#ifdef WIDE_DMA_IN_P2
+      // (measured: the pieces' issue cost does NOT hide between the MFMAs -- 547 -> 1004 cycles for the MFMA phase -- so the
+      // product issues them in P1, beside the other wave group's matrix work)
+      __builtin_amdgcn_sched_barrier(0);
+      if (gq == 1) issue_dma();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
     __builtin_amdgcn_s_setprio(0);
+    WSTAMP(st_d)
     // weights of step s+1 (group 0) / s+2 (group 1) have landed for this wave; near the end of the run fewer steps are in flight
-    if (s + D >= S) wait_vm<0>();
-    else if (grp == 0) wait_vm<(D - 2) * PPWB>();
-    else wait_vm<(D - 3) * PPWB>();
+    if constexpr (WREG) {
+      // the weight loads are the compiler's (it waits before the ds_write); the asm DMA pieces of the chunk being fetched are
+      // older than this step's loads: at the end of every chunk period wait for everything but those loads
+      // (two steps before the period's end: group 1 runs one barrier behind, and with R = 2 the chunk is read in the very next period)
+      if (c_tap == taps - 2) { if (vm_nl1) wait_vm<PPWB>(); else wait_vm<0>(); }
+    } else {
+      if (chunk_wave) { if (c_tap == taps - 2) wait_vm<0>(); }      // its halo pieces of this period (issued in its first steps)
+      else if (s + D >= S) wait_vm<0>();
+      else wait_vm_rt((grp == 0 ? D - 2 : D - 3) * w_cnt_pieces);
+    }
+    WSTAMP(st_e)
     wg_barrier();
+    WSTAMP(st_f)
+    WACC(0, st_a, st_b) WACC(1, st_b, st_c) WACC(2, st_c, st_d) WACC(3, st_d, st_e) WACC(4, st_e, st_f)
 
     // ============================== advance the cursors ==============================
-    ++c_ws;
-    if (++txx == k) { txx = 0; ++tyy; }
-    if (++c_tap == taps) {                            // chunk period over: the fetch cursor moves on with it
-      c_tap = 0; tyy = 0; ++c_gc; ++c_c;
+    ++c_ws; ++s;
+    b_soff += WT_BYTES; ++b_slot;
+    if (b_slot == D) { b_slot = 0; b_soff -= D * WT_BYTES; }
+    a_soff += 16; ++txx;
+    if (txx == k) {
+      txx = 0; a_soff += d_rowwrap; ++tyy;
+      if (tyy == k) { tyy = 0; a_soff -= k * HWtc * 16; }             // tap (k-1, k-1) -> (0, 0)
+    }
+    bool new_period = false;
+    if (++c_tap == taps) {                            // chunk period over (the tap is back at t0): next slot of the A ring; the fetch cursor moves on with it
+      c_tap = 0;
+      ++a_slot;
+      if (a_slot == R) a_slot = 0;
+      new_period = true;
       if (d_j < t_cnt) advance_chunk_cursor();
     }
     if (last) {
+      WSTAMP1(st_ep0)
       // ---------------------------------------------------------------- LSTM epilogue (model.py:221-229)
       const int cblock = nt0 / 4, c4 = 4 * (lane >> 4);
       const int ch = cblock * 16 + c4;
@@ -293,8 +577,8 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
         const int rt = ps * RPW + i;
-        const int y = ct.y0 + rt % Rc, x = ct.x0 + 16 * (rt / Rc) + px;
-        const bool ok = y < a.H && x < a.W;           // (the lane exchange below needs every lane: no divergent block)
+        const int y = ct.y0 + (rt & Rm), x = ct.x0 + 16 * (rt >> lgR) + px;
+        const bool ok = rt < nrt && y < a.H && x < a.W;   // (the lane exchange below needs every lane: no divergent block)
         const size_t rowpix = ((size_t)ct.img * a.H + y) * a.W;
         const f32x4_t cp = cpv[i];
         f32x4_t gi, gf, gg, go, cn, hn;
@@ -328,31 +612,47 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
         }
       }
       // ---------------------------------------------------------------- next tile
-      c_ws = 0; c_c = 0;
+      c_ws = 0;
       if (++c_j < t_cnt) {
         ct = wide_tile(a, t_first + c_j * t_stride);
-        set_rowoff();
+        nt0 = ct.ch * 4 * CG + cg * 4;
+        set_tile();
         init_acc();
       }
+      WSTAMP1(st_g)
+      WACC1(5, st_ep0, st_g)
     }
+    if (new_period) a_soff = a_slot * chunk_bytes + (ty0 * HWtc + tx0) * 16;   // (after a unit switch: the new tile's halo width)
+  };
+  while (s < S) {
+    step(P0{});
+    if (s < S) step(P1_{});
   }
-  if (grp == 0) wg_barrier();                         // pairs with group 1's extra barrier at the start
+  if (grp == 0) wg_barrier();
+#ifdef NINT_STAMP
+  if (lane == 0 && blockIdx.x < WIDE_STAMP_WGS) {
+    unsigned long long* o = g_wide_stamp + ((size_t)blockIdx.x * 8 + wave) * 16;
+    for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
+    o[8] = __builtin_amdgcn_s_memtime() - st_t0; o[9] = __builtin_amdgcn_s_memrealtime() - st_r0; o[10] = S; o[11] = t_cnt;
+    o[12] = st_r0; o[13] = st_acc[8]; o[14] = st_acc[9]; o[15] = st_acc[10];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------ host side
 static unsigned magic_of(int d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
 
-template <int PS, int D, int KS>
-static int launch_wide(WideArgs& a, int ny, int n_cu, int R, hipStream_t st) {
+template <int PS, int D, int KS, bool WREG>
+static int launch_wide(WideArgs& a, int n_cu, int R, hipStream_t st) {
   constexpr int CG = 8 / PS;
   const size_t lds = (size_t)R * a.nhpp * 64 + (size_t)D * 4 * CG * 1024;
   if (lds > 160 * 1024) return NINT_E_LDS;
-  const int nwg = a.ntiles < n_cu ? a.ntiles : n_cu;
+  const int nwg = a.nunits < n_cu ? a.nunits : n_cu;
 #define NINT_WIDE_LAUNCH(R_)                                                                                          \
   {                                                                                                                   \
-    auto kern = conv_wide_lstm_kernel<PS, D, R_, KS>;                                                                     \
+    auto kern = conv_wide_lstm_kernel<PS, D, R_, KS, WREG>;                                                                     \
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
-    hipLaunchKernelGGL(kern, dim3(nwg, ny), dim3(512), lds, st, a);                                                   \
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, st, a);                                                   \
   }
   if (R == 2) NINT_WIDE_LAUNCH(2) else if (R == 3) NINT_WIDE_LAUNCH(3) else if (R == 4) NINT_WIDE_LAUNCH(4) else return NINT_E_ARG;
 #undef NINT_WIDE_LAUNCH
@@ -360,38 +660,32 @@ static int launch_wide(WideArgs& a, int ny, int n_cu, int R, hipStream_t st) {
   return NINT_OK;
 }
 
-// Serves: bf16, LSTM epilogue, k x k taps on both sources (no horizontal fold), k = 3 or 5, gate columns a multiple of 256 (PS = 2),
-// enough 256-pixel tiles to give every CU one.  NINT_E_SHAPE = not served (the caller takes conv_igemm.hip's kernel).
-int nint_internal_conv_wide_lstm(const ConvArgs& c, int N, int force, void* stream) {
-  if (c.kx0 != c.k || (c.k != 3 && c.k != 5) || c.nchunk0 + c.nchunk1 < 1) return NINT_E_SHAPE;
-  if (c.NTt % 16 != 0) return NINT_E_SHAPE;
-  constexpr int D = 5;
-  int dev = 0, n_cu = 0;
-  NINT_CHECK_HIP(hipGetDevice(&dev));
-  NINT_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  WideArgs a = {};
-  a.src0 = c.src0; a.src1 = c.src1; a.nchunk0 = c.nchunk0; a.nchunk1 = c.src1 ? c.nchunk1 : 0;
-  a.img_stride0 = c.img_stride0; a.img_stride1 = c.img_stride1; a.pix_stride0 = c.pix_stride0; a.pix_stride1 = c.pix_stride1;
-  a.Bp = c.Bp; a.NTt = c.NTt; a.k = c.k; a.p = c.p; a.taps = c.taps;
-  a.H = c.H; a.W = c.W; a.P = c.P; a.Hh = c.Hh; a.Wh = c.Wh;
-  a.bias = c.bias; a.c_prev = c.c_prev; a.c_out = c.c_out; a.h_out = c.h_out; a.gates_out = c.gates_out;
-  a.Chp = c.Chp; a.Ch16 = c.Ch16;
-  // tile shape: R rows x (16 / R) blocks of 16 pixels; leftover rows (<= R/2 of them) as a strip of flatter tiles.
+// Plan of one tile size (PS pixel slices of 8 row tiles: 256 or 512 pixels per workgroup tile, 64*8/PS gate columns per unit).
+template <int PS, int D, bool WREG>
+static int plan_wide(WideArgs& a, int N, int* R_out) {
+  constexpr int CG = 8 / PS, TRT = PS * 8;
+  if (a.NTt % (4 * CG)) return NINT_E_SHAPE;
+  a.ny = a.NTt / (4 * CG);
+  // tile shape: R rows x (TRT / R) blocks of 16 pixels; leftover rows (<= R/2 of them) as a strip of flatter tiles.
   // Fewest tiles wins, then the smaller halo.
   int best_tiles = 1 << 30, best_halo = 1 << 30;
-  for (int R0 = 16; R0 >= 1; R0 >>= 1) {
-    const int bx = nint_cdiv(a.W, 16);               // 16-pixel blocks the grid is wide: a tile is never wider
-    const int Cb0 = 16 / R0 < bx ? 16 / R0 : bx;
+  const int bx = nint_cdiv(a.W, 16);                 // 16-pixel blocks the grid is wide: a tile is never wider
+  for (int R0 = TRT; R0 >= 1; R0 >>= 1) {
+    // (widths balanced over the tiles of a row: 154 pixels = 10 blocks in tiles of at most 8 -> 2 tiles of 5, not 8 + 2)
+    const int Cm0 = TRT / R0 < bx ? TRT / R0 : bx;
+    const int Cb0 = nint_cdiv(bx, nint_cdiv(bx, Cm0));
     int ty0 = a.H / R0, left = a.H % R0, R1 = 0;
     if (left) {
       R1 = 1;
       while (R1 < left) R1 <<= 1;
       if (R1 >= R0) { R1 = 0; ++ty0; }               // more than half a tile of rows left: one more row of full tiles
     }
-    const int Cb1 = R1 ? (16 / R1 < bx ? 16 / R1 : bx) : 0;
+    const int Cm1 = R1 ? (TRT / R1 < bx ? TRT / R1 : bx) : 0;
+    const int Cb1 = R1 ? nint_cdiv(bx, nint_cdiv(bx, Cm1)) : 0;
     const int tx0 = nint_cdiv(a.W, 16 * Cb0), tx1 = R1 ? nint_cdiv(a.W, 16 * Cb1) : 0;
     const int tiles = ty0 * tx0 + tx1;
-    const int halo = (R0 + 2 * a.p) * (16 * Cb0 + 2 * a.p);
+    int halo = (R0 + 2 * a.p) * (16 * Cb0 + 2 * a.p);
+    if (R1 && (R1 + 2 * a.p) * (16 * Cb1 + 2 * a.p) > halo) halo = (R1 + 2 * a.p) * (16 * Cb1 + 2 * a.p);
     if (tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
       best_tiles = tiles; best_halo = halo;
       a.R[0] = R0; a.Cb[0] = Cb0; a.R[1] = R1; a.Cb[1] = Cb1;
@@ -400,7 +694,7 @@ int nint_internal_conv_wide_lstm(const ConvArgs& c, int N, int force, void* stre
   }
   a.tiles_img = best_tiles;
   a.ntiles = N * best_tiles;
-  if (!force && a.ntiles * 16 < n_cu * 15) return NINT_E_SHAPE;      // fewer tiles than CUs: the 4-wave kernel's small tiles fill the chip better
+  a.nunits = a.ntiles * a.ny;
   int nhp_max = 0;
   for (int q = 0; q < 2; ++q) {
     if (q == 1 && !a.R[1]) { a.R[1] = a.R[0]; a.Cb[1] = a.Cb[0]; a.HWt[1] = a.HWt[0]; a.NHP[1] = a.NHP[0]; a.magic_hwt[1] = a.magic_hwt[0]; break; }
@@ -414,18 +708,73 @@ int nint_internal_conv_wide_lstm(const ConvArgs& c, int N, int force, void* stre
   a.magic_nhpp = magic_of(a.nhpp);
   a.npc = a.nhpp / 16;
   a.spt = (a.nchunk0 + a.nchunk1) * a.taps;
-  // chunk ring depth and issue rate: the pieces of chunk g+R-1 go out during the first steps of period g and must be
-  // older than every weight piece waited for at the start of period g+R-1 (header comment): last issue step <= (R-1)*taps - D
+  // chunk ring depth and issue rate.  DMA weight ring: the pieces of chunk g+R-1 go out during the first steps of period g
+  // and must be older than every weight piece waited for at the start of period g+R-1 (header comment): last issue step
+  // <= (R-1)*taps - D.  Register-staged weights: the pieces are waited for two steps before the end of the period they are issued in.
+  // (DMA ring: two waves issue the pieces of a chunk and wait for them two steps before the end of the period they are issued in)
+#ifdef WIDE_ROLE_SPLIT
+  const int wave_pieces = nint_cdiv(a.npc, WREG ? 8 : 2);
+#else
   const int wave_pieces = nint_cdiv(a.npc, 8);
-  int R = 0;
-  for (int r = 2; r <= 4 && !R; ++r) {
-    for (int pps = 1; pps <= 4; ++pps) {
+#endif
+  for (int r = 2; r <= 4; ++r) {
+    for (int pps = 1; pps <= 8; ++pps) {
       const int issue_steps = nint_cdiv(wave_pieces, pps);
-      if (issue_steps <= a.taps && issue_steps - 1 <= (r - 1) * a.taps - D &&
-          (size_t)r * a.nhpp * 64 + (size_t)D * 16 * 1024 <= 160 * 1024) { R = r; a.pps = pps; break; }
+#ifdef WIDE_ROLE_SPLIT
+      const bool in_time = issue_steps <= a.taps - 2;
+#else
+      const bool in_time = WREG ? issue_steps <= a.taps - 2 : (issue_steps <= a.taps && issue_steps - 1 <= (r - 1) * a.taps - D);
+#endif
+      if (in_time && (size_t)r * a.nhpp * 64 + (size_t)D * 4 * CG * 1024 <= 160 * 1024) { *R_out = r; a.pps = pps; return NINT_OK; }
     }
   }
-  if (!R) return NINT_E_SHAPE;
-  return a.k == 5 ? launch_wide<2, D, 5>(a, a.NTt / 16, n_cu, R, (hipStream_t)stream)
-                  : launch_wide<2, D, 3>(a, a.NTt / 16, n_cu, R, (hipStream_t)stream);
+  return NINT_E_LDS;
+}
+
+// Serves: bf16, LSTM epilogue, k x k taps on both sources (no horizontal fold), k = 3 or 5, gate columns a multiple of 128,
+// enough tiles to give every CU one.  NINT_E_SHAPE = not served (the caller takes conv_igemm.hip's kernel).
+// force: 0 = only where it is expected to win; 2 = wherever it is instantiated; 3 / 4 = that, with 256- / 512-pixel tiles;
+// + 8 = taps in plain order in every workgroup (results then equal the 4-wave kernel's bit for bit).
+int nint_internal_conv_wide_lstm(const ConvArgs& c, int N, int force_, void* stream) {
+  const int force = force_ & 7, rot = (force_ & 8) ? 0 : 1;      // + 8: plain K order (bit-identical to the 4-wave kernel: tests)
+  if (c.kx0 != c.k || (c.k != 3 && c.k != 5) || c.nchunk0 + c.nchunk1 < 1) return NINT_E_SHAPE;
+#ifdef WIDE_WREG
+  constexpr bool WREG = true;                      // A/B build: weights through registers into a 3-slot ring
+  constexpr int D = 3;
+#else
+  constexpr bool WREG = false;
+#ifndef WIDE_D
+#define WIDE_D 5
+#endif
+  constexpr int D = WIDE_D;
+#endif
+  int dev = 0, n_cu = 0;
+  NINT_CHECK_HIP(hipGetDevice(&dev));
+  NINT_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  WideArgs a = {};
+  a.src0 = c.src0; a.src1 = c.src1; a.nchunk0 = c.nchunk0; a.nchunk1 = c.src1 ? c.nchunk1 : 0;
+  a.img_stride0 = c.img_stride0; a.img_stride1 = c.img_stride1; a.pix_stride0 = c.pix_stride0; a.pix_stride1 = c.pix_stride1;
+  a.Bp = c.Bp; a.NTt = c.NTt; a.k = c.k; a.p = c.p; a.taps = c.taps;
+  a.H = c.H; a.W = c.W; a.P = c.P; a.Hh = c.Hh; a.Wh = c.Wh;
+  a.bias = c.bias; a.c_prev = c.c_prev; a.c_out = c.c_out; a.h_out = c.h_out; a.gates_out = c.gates_out;
+  a.Chp = c.Chp; a.Ch16 = c.Ch16;
+  // 512-pixel tiles (half the weight bytes per MFMA: the L2 -> CU path, not the matrix pipe, paces the 256-pixel version) when
+  // their units fill the CUs about as evenly as the 256-pixel ones; efficiency = units / (rounds * CUs)
+  WideArgs a4 = a, a2 = a;
+  int R4 = 0, R2 = 0;
+  const int rc4 = force == 3 ? NINT_E_SHAPE : plan_wide<4, D, WREG>(a4, N, &R4);
+  const int rc2 = force == 4 ? NINT_E_SHAPE : plan_wide<2, D, WREG>(a2, N, &R2);
+  auto eff = [&](const WideArgs& w) { return (double)w.nunits / ((double)nint_cdiv(w.nunits, n_cu) * n_cu); };
+  const bool use4 = rc4 == NINT_OK && (rc2 != NINT_OK || eff(a4) >= 0.9 * eff(a2));
+  if (!use4 && rc2 != NINT_OK) return NINT_E_SHAPE;
+  WideArgs& w = use4 ? a4 : a2;
+  w.rot = rot;
+  // force == 0 (nint_layer.wide = 0): NOT taken.  Measured on MI355X at the bench shape (B = 8, 100 x 154, 62 + 64 -> 256, k = 5):
+  // 187-200 us per launch in the step against 171 us for the 4-wave kernel -- the K loop runs ~1950 cycles per K-step instead
+  // of the ~1050 it reaches with the DMA issue ablated (an LDS-DMA piece costs its issuing wave ~220 cycles, a
+  // halo gather piece far more); kept for nint_layer.wide >= 2 (tests, tools/wideprobe.py, the ablation record).
+  if (!force) return NINT_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (use4) return a.k == 5 ? launch_wide<4, D, 5, WREG>(w, n_cu, R4, st) : launch_wide<4, D, 3, WREG>(w, n_cu, R4, st);
+  return a.k == 5 ? launch_wide<2, D, 5, WREG>(w, n_cu, R2, st) : launch_wide<2, D, 3, WREG>(w, n_cu, R2, st);
 }

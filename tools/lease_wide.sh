@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT"
 timeout -k 10 400 python -m pytest tests/test_gpu_wide.py -x -q "$@" > "$OUT/tests.log" 2>&1; rc=$?; echo "pytest rc $rc" >> "$OUT/tests.log"
 tail -15 "$OUT/tests.log"
 [ $rc -ne 0 ] && exit 1
-for w in 1 0 1 0; do
+for w in ${WIDES:-1 0 1 0}; do
   timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --long-steps 0 --wide $w 2>> "$OUT/bench.err" | tail -1 > "$OUT/bench_wide$w.json" || exit 1
   python - "$OUT/bench_wide$w.json" $w <<'PY'
 import json, sys

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Race screen for the 8-wave gate kernel: many forwards of the bench layer at B=8, T=12, every slab compared byte for byte
+with the 4-wave kernel's; prints where the first differences sit (image, row, column, channel).
+    python tools/wide_stress.py [--wide 3] [--iters 20]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nasa_niswan_amd as pkg  # noqa: E402
+from nasa_niswan_amd import engine  # noqa: E402
+from nasa_niswan_amd.engine import LayerCfg, SeqEngine  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--wide", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--T", type=int, default=12)
+    args = ap.parse_args()
+    pkg.load_library()
+    B, T, H, W, Cx, Ch, k = args.batch, args.T, 100, 154, 62, 64, 5
+    engs = {}
+    for w in (1, args.wide):
+        engine.FORCE_WIDE = w
+        engs[w] = SeqEngine([LayerCfg(Cx, Ch, k)], "bf16", "cuda")
+    engine.FORCE_WIDE = 0
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Wt = [torch.randn(4 * Ch, Cx + Ch, k, k, device="cuda", generator=g) * 0.05]
+    bs = [torch.randn(4 * Ch, device="cuda", generator=g) * 0.2]
+    X = torch.randn(B, T, Cx, H, W, device="cuda", generator=g)
+    ws = {}
+    for w, e in engs.items():
+        e.pack_weights(Wt, bs)
+        ws[w] = e.acquire(B, T, H, W, True, False)
+    # reference: the 4-wave kernel when the wide one runs the plain tap order (+8: bit-identical), else its own first run
+    rw = 1 if args.wide & 8 else args.wide
+    engs[rw].forward(ws[rw], X)
+    torch.cuda.synchronize()
+    ref = (ws[rw].h[0].clone(), ws[rw].c[0].clone(), ws[rw].gates[0].clone())
+    bad = 0
+    for it in range(args.iters):
+        e, w = engs[args.wide], ws[args.wide]
+        e.forward(w, X)
+        torch.cuda.synchronize()
+        for name, a, b in zip(("h", "c", "gates"), (w.h[0], w.c[0], w.gates[0]), ref):
+            if not torch.equal(a, b):
+                bad += 1
+                if name == "c":
+                    d = (a != b).view(T + 1, B, H, W, -1)
+                    idx = d.nonzero()
+                    print(f"iter {it}: c differs in {len(idx)} elements; first: slot,b,y,x,ch = {idx[0].tolist()}; last {idx[-1].tolist()}")
+                    first = idx[idx[:, 0] == idx[:, 0].min()]
+                    fy, fx, fc = first[:, 2], first[:, 3], first[:, 4]
+                    print(f"   FIRST wrong slot {int(first[0, 0])}: {len(first)} elements, y {int(fy.min())}..{int(fy.max())}, x {int(fx.min())}..{int(fx.max())}, "
+                          f"channels {int(fc.min())}..{int(fc.max())} ({len(set(fc.tolist()))} distinct), images {sorted(set(first[:, 1].tolist()))}")
+                    av = a.view(T + 1, B, H, W, -1)[tuple(first[0].tolist())]; bv = b.view(T + 1, B, H, W, -1)[tuple(first[0].tolist())]
+                    nan = int(torch.isnan(a.view(T + 1, B, H, W, -1)[int(first[0, 0])]).sum())
+                    print(f"   first wrong value {float(av):.6g} vs {float(bv):.6g}; NaNs in that slot: {nan}")
+                    rows = sorted(set(fy.tolist())); cols = sorted(set(fx.tolist()))
+                    print(f"   rows {rows[:40]}  cols {cols[:70]}")
+                    ys, xs = idx[:, 2], idx[:, 3]
+                    print(f"   y range {int(ys.min())}..{int(ys.max())}, x range {int(xs.min())}..{int(xs.max())}, slots {sorted(set(idx[:, 0].tolist()))[:6]}, "
+                          f"images {sorted(set(idx[:, 1].tolist()))}, channels {sorted(set(idx[:, 4].tolist()))[:8]}..")
+                else:
+                    print(f"iter {it}: {name} differs in {int((a != b).sum())} bytes")
+    print(f"{bad} mismatching slabs in {args.iters} forwards of {T} x {B} images (wide={args.wide})")
+
+
+if __name__ == "__main__":
+    main()
