@@ -162,6 +162,7 @@ def parse_args(argv=None):
     ap.add_argument("--wide", type=int, default=0, help="nint_layer.wide of every layer (0 = the library's choice, 1 = 4-wave kernels, 2 = 8-wave LDS-weight kernel)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--lib", default=None, help="load this build of the library (A/B copies made by nasa-niswan_amd/build.py --out=...) instead of the product one")
     return ap.parse_args(argv)
 
 
@@ -241,7 +242,7 @@ def main():
     from nasa_niswan_amd import engine as _engine
     _engine.FUSE_BWD = args.fuse_bwd
     _engine.FORCE_WIDE = args.wide
-    pkg.load_library()
+    pkg.load_library(args.lib) if args.lib else pkg.load_library()
 
     C, hidden, ks, out, T, Hp, Wp, halo, grid = WORKLOADS[args.workload]
     if args.scaling == "strong":

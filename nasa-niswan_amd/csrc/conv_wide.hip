@@ -718,7 +718,10 @@ static int plan_wide(WideArgs& a, int N, int* R_out) {
   const int wave_pieces = nint_cdiv(a.npc, 8);
 #endif
   for (int r = 2; r <= 4; ++r) {
-    for (int pps = 1; pps <= 8; ++pps) {
+#ifndef WIDE_PPS_MIN
+#define WIDE_PPS_MIN 1
+#endif
+    for (int pps = (WIDE_PPS_MIN < wave_pieces ? WIDE_PPS_MIN : wave_pieces); pps <= 8; ++pps) {
       const int issue_steps = nint_cdiv(wave_pieces, pps);
 #ifdef WIDE_ROLE_SPLIT
       const bool in_time = issue_steps <= a.taps - 2;

@@ -27,7 +27,7 @@ def _forward_slabs(Cx, hidden, ks, B, T, H, W, wide, seed):
     engine.FORCE_WIDE = wide
     # the 4-wave reference with its launch shape pinned (8-row tiles, all gate columns in one workgroup: no K slices): small
     # batches would otherwise split the columns over workgroups whose waves slice K -- another summation order
-    engine.FORCE_TILE_ROWS = 8 if wide == 1 else 0
+    engine.FORCE_TILE_ROWS = 8          # (for every engine: layers the wide kernel does not serve fall back to the 4-wave one)
     try:
         eng = SeqEngine([LayerCfg(Cx if l == 0 else hidden[l - 1], hidden[l], ks[l]) for l in range(len(hidden))], "bf16", "cuda")
     finally:
