@@ -540,8 +540,12 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
       // (two steps before the period's end: group 1 runs one barrier behind, and with R = 2 the chunk is read in the very next period)
       if (c_tap == taps - 2) { if (vm_nl1) wait_vm<PPWB>(); else wait_vm<0>(); }
     } else {
+      // The counted wait is exact only among operations of ONE kind: the register-staged experiment (WREG) showed that an
+      // LDS-DMA piece can complete, and decrement vmcnt, before an OLDER plain load.  Around a unit's end this wave also has
+      // plain loads (c_{t-1}, the next unit's bias) and the epilogue's stores in flight, so there -- the unit's last step and
+      // the D steps behind the epilogue -- and at the end of the run the wait is a full drain.
       if (chunk_wave) { if (c_tap == taps - 2) wait_vm<0>(); }      // its halo pieces of this period (issued in its first steps)
-      else if (s + D >= S) wait_vm<0>();
+      else if (s + D >= S || last || (c_j > 0 && c_ws < D)) wait_vm<0>();
       else wait_vm_rt((grp == 0 ? D - 2 : D - 3) * w_cnt_pieces);
     }
     WSTAMP(st_e)
