@@ -78,8 +78,10 @@ def test_shapes_vs_oracle(pkg, name, dtype):
 def test_full_size_properties(pkg):
     """100x154 padded grid, T=12, C=62, out=20 (the bench workload) at B=2: size-independent properties
     on top of the oracle comparison at this size (tests/test_gpu_fullsize.py): run-to-run bitwise
-    determinism, batch independence (a sample's result does not depend on its batch mates) and
-    agreement of the f32 and bf16 paths."""
+    determinism, batch independence (a sample's result does not depend on its batch mates: bit for bit while the launch
+    shape is pinned -- small batches otherwise take smaller tiles / split gate columns, i.e. another f32 summation order,
+    and agree to rounding) and agreement of the f32 and bf16 paths."""
+    from nasa_niswan_amd import engine
     torch.manual_seed(0)
     C, hidden, ks, out, B, T, H, W = 62, [64, 32, 16], [5, 3, 3], 20, 2, 12, 100, 154
     X = torch.randn(B, T, C, H, W, device="cuda")
@@ -101,7 +103,19 @@ def test_full_size_properties(pkg):
                 assert torch.equal(pred, outs[dt]) and torch.equal(g, grads[dt]), f"{dt}: not deterministic"
         with torch.no_grad():
             single = net(X[1:2])
-        assert torch.equal(single, outs[dt][1:2]), f"{dt}: batch dependence"
+        rel = float((single - outs[dt][1:2]).norm() / outs[dt][1:2].norm())
+        assert rel <= (1e-6 if dt == "f32" else 5e-3), f"{dt}: batch dependence {rel}"
+    # ... and bit for bit with the tile height pinned (engines are built per module: fresh modules, same weights)
+    engine.FORCE_TILE_ROWS = 8
+    try:
+        for dt in ("f32", "bf16"):
+            torch.manual_seed(1)
+            net = pkg.ConvLSTM(C, hidden, ks, 3, out_channels=out, compute_dtype=dt).cuda()
+            with torch.no_grad():
+                both, single = net(X), net(X[1:2])
+            assert torch.equal(single, both[1:2]), f"{dt}: batch dependence with the launch shape pinned"
+    finally:
+        engine.FORCE_TILE_ROWS = 0
     r = float((outs["bf16"] - outs["f32"]).norm() / outs["f32"].norm())
     rg = float((grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm())
     print(f"  bf16 vs f32 at full size: pred rel-L2 {r:.2e}, grads rel-L2 {rg:.2e}")
