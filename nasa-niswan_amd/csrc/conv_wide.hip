@@ -1,25 +1,30 @@
 // conv_wide.hip -- the gate convolution of the WIDE ConvLSTM layers as a persistent 8-wave implicit GEMM whose
 // weight tiles go through LDS once per workgroup (gfx950, bf16).            reference: model.py:219-229
 //
+// OPT-IN (nint_layer.wide >= 2): bit-identical to conv_igemm.hip's 4-wave kernel, a third less traffic on the texture path,
+// and 10-17 % SLOWER at the bench shape -- DESIGN.md 4.5 and profiles/r03_b_* hold the stamp / PMC record of why.  Kept
+// for that record's tools (tools/wideprobe.py, tools/wide_stress.py) and tests (tests/test_gpu_wide.py).
+//
 // conv_igemm.hip's 4-wave kernel streams every wave's own weight fragments L2 -> L1 -> VGPR: for the reference's layer 0
 // (Conv2d(62+64 -> 256, k=5)) that is 1.66 GB of on-chip weight traffic per launch through the texture path (TD busy
 // 72 % of the launch, profiles/r02_b_pmc_memory_path_counters.txt), and its 1000 workgroups run their fill / K loop /
 // epilogue phases in two chip-wide rounds.  This kernel restructures the same arithmetic:
 //
-//   * a workgroup = 8 waves = PS pixel slices x CG column groups (PS*CG = 8) owns a 256-PIXEL tile (16 row tiles of 16
-//     pixels: R rows x Cb blocks, R*Cb = 16) and 64*CG gate columns; a wave computes 16/PS row tiles x 4 column tiles
-//     (one hidden-channel block: its i,f,g,o tiles share lanes, as in conv_igemm.hip).
+//   * a workgroup = 8 waves = PS pixel slices x CG column groups (PS*CG = 8); a wave computes 8 row tiles of 16 pixels x
+//     4 column tiles (one hidden-channel block: its i,f,g,o tiles share lanes, as in conv_igemm.hip).  A UNIT of work =
+//     one pixel tile of TRT = 8*PS row tiles (256 or 512 pixels: R rows x Cb blocks of 16, R a power of two) x one set of
+//     64*CG gate columns; the column-group sets of a pixel tile are consecutive units.
 //   * B: the K-step's weight tile (4*CG KiB, already in MFMA fragment order in global memory) is copied ONCE per
 //     workgroup by LDS-DMA (global_load_lds_dwordx4, every wave issues its share) into a D-slot ring, D-1 steps ahead;
 //     all PS pixel slices read their fragments from there (ds_read_b128, lane-linear: conflict-free).
 //   * A: the halo tile is staged per 64-byte channel CHUNK into an R-slot ring: while the K loop runs the taps of chunk c,
-//     the pieces of chunk c+R-1 -- of this tile or of the workgroup's NEXT tile -- arrive by LDS-DMA.  The workgroup is
-//     PERSISTENT (one per CU, tiles dealt in XCD-contiguous ranges), so only its very first chunks are waited for; every
-//     other fill, and the weights of the next tile's first steps, travel under MFMA work.
-//   * synchronisation: raw s_barrier + counted s_waitcnt vmcnt(N), never 0 inside the loop.  All waves run the same
-//     program, {P1: issue DMA, read fragments | barrier | P2: MFMAs, counted wait | barrier} per K-step, but waves 4-7
+//     the pieces of chunk c+R-1 -- of this unit or of the workgroup's NEXT unit -- arrive by LDS-DMA.  The workgroup is
+//     PERSISTENT (one per CU, units dealt in XCD-contiguous ranges), so only its very first chunks are waited for.
+//   * synchronisation: raw s_barrier + counted s_waitcnt vmcnt(N).  All waves run the same program,
+//     {P1: issue DMA, read fragments | barrier | P2: MFMAs, counted wait | barrier} per K-step, but waves 4-7
 //     (the second wave of every SIMD) run ONE BARRIER BEHIND waves 0-3: while one wave of a SIMD holds the matrix pipe the
 //     other one reads LDS and issues DMA (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+//   * all per-step bookkeeping is incremental scalar state: no division, multiplication or kernel-argument reload in the loop.
 //   * the LSTM epilogue is conv_igemm.hip's (D = [channel][pixel], 16 / 8-byte vectors, bias in the accumulator init);
 //     c_{t-1} is fetched one K-step ahead of it.
 //
@@ -28,15 +33,18 @@
 //   RAW weights of step s: read by group 0 after beta_2s-1.  Every wave waits for ITS pieces of step s before that
 //       barrier: group 0 in P2(s-1) (N = (D-2) steps' pieces may stay in flight), group 1 in P2(s-2) (N = D-3 steps').
 //   WAR weight slot of step s (reused by step s+D): last read by group 1 in P1(s), before beta_2s+1; step s+D is issued
-//       in P1(s+1), after beta_2s+1 (group 0) / beta_2s+2 (group 1).
+//       in P1(s+1), after beta_2s+1 (group 0) / beta_2s+2 (group 1).  (The fragment reads of P1 are consumed by the MFMAs of
+//       P2, so they may still be in flight one interval later; a DMA piece issued then lands hundreds of cycles after them.)
 //   RAW chunk g+R-1: its pieces are issued in the first steps of chunk period g, BEFORE the weight pieces of the same
 //       step, so they are older than every weight piece that is waited for at the start of period g+R-1 (the host checks
 //       that the issue steps end D steps before that period).  WAR: the slot held chunk g-1, whose last read (group 1) is
 //       before the first barrier of period g.
-// hipcc does not know about the inline-asm DMA (it counts neither their vmcnt nor their LDS writes); its own counted waits
-// for the epilogue's loads stay correct because vmcnt retires in order (extra older / younger operations only make a
-// compiler-computed wait more conservative).
-#include <type_traits>
+//   The counted waits are exact only among LDS-DMA pieces: a register-staged variant of the weight path (plain loads +
+//   ds_write, removed) showed that a DMA piece can complete, and decrement vmcnt, before an OLDER plain load.  Around a unit's
+//   end this wave also has plain loads (c_{t-1}, the next unit's bias) and the epilogue's stores in flight, so there -- the
+//   unit's last step and the D steps behind the epilogue -- and at the end of the run the wait is a full drain.
+// hipcc does not know about the inline-asm DMA (it counts neither their vmcnt nor their LDS writes); its own waits for the
+// epilogue's loads only ever become more conservative by operations it does not see.
 #include "nint_common.h"
 
 struct WideArgs {
@@ -55,7 +63,7 @@ struct WideArgs {
   int nhpp;                                    // pixels per g-plane of a chunk slot (>= NHP of both classes, multiple of 16)
   unsigned magic_nhpp;
   int npc, pps;                                // 1-KiB pieces per chunk; pieces per wave per K-step while a chunk is being fetched
-  int spt;                                     // K-steps per tile
+  int spt;                                     // K-steps per unit
   int rot;                                     // 1: every workgroup starts the taps of a chunk at its own tap (blockIdx.x % taps)
   const float* bias; const float* c_prev; float* c_out; char* h_out; char* gates_out;
   int Chp, Ch16;
@@ -111,78 +119,18 @@ __device__ __forceinline__ WTile wide_tile(const WideArgs& a, int u) {
 
 // One 1-KiB LDS-DMA piece: lane l copies 16 bytes from gsrc (per lane) to lds_dst + 16*l (wave-uniform base in M0).
 // M0 is written and NOT restored: nothing else in this translation unit's kernels uses M0 (gfx950 LDS instructions do not;
-// tools/regs.py --m0 audits the ISA), and a restore right behind the DMA would be a second M0 write that has to wait for
-// the DMA to have read it.
+// checked in the ISA: no other m0 operand).
 __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
-#ifdef WIDE_ABL_FIXEDM0      // timing experiment (wrong results): no M0 write in front of the DMA
-  asm volatile("global_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
-#else
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
-#endif
 }
 // two consecutive pieces (global +1024, LDS +1024: the instruction offset applies to both addresses) behind ONE M0 write
 __device__ __forceinline__ void glds16x2(const char* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
                : : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-// A 16-byte load the compiler does not count (so that it cannot drain the queue with vmcnt(0) at the next control-flow join):
-// the destination is valid only behind wait_vm_regs<N>(), which names it "+v" (cdna_hip_programming.md 5.7 item 1, form (ii)).
-__device__ __forceinline__ void gload16_asm(u32x4_t& dst, const char* src) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm_regs(u32x4_t& r0) {
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "n"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm_regs(u32x4_t& r0, u32x4_t& r1) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N) : "memory");
-}
-// the same with a wave-uniform run-time count (0 .. 10): a scalar branch to the matching immediate
-#define NINT_VMCASE(K, ...) case K: asm volatile("s_waitcnt vmcnt(" #K ")" : __VA_ARGS__ : : "memory"); break;
-__device__ __forceinline__ void wait_vm_regs_rt(int n, u32x4_t& r0) {
-  switch (n) {
-    NINT_VMCASE(1, "+v"(r0)) NINT_VMCASE(2, "+v"(r0)) NINT_VMCASE(3, "+v"(r0)) NINT_VMCASE(4, "+v"(r0)) NINT_VMCASE(5, "+v"(r0))
-    NINT_VMCASE(6, "+v"(r0)) NINT_VMCASE(7, "+v"(r0)) NINT_VMCASE(8, "+v"(r0)) NINT_VMCASE(9, "+v"(r0)) NINT_VMCASE(10, "+v"(r0))
-    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0) : : "memory"); break;
-  }
-}
-__device__ __forceinline__ void wait_vm_regs_rt(int n, u32x4_t& r0, u32x4_t& r1) {
-  switch (n) {
-    NINT_VMCASE(1, "+v"(r0), "+v"(r1)) NINT_VMCASE(2, "+v"(r0), "+v"(r1)) NINT_VMCASE(3, "+v"(r0), "+v"(r1)) NINT_VMCASE(4, "+v"(r0), "+v"(r1))
-    NINT_VMCASE(5, "+v"(r0), "+v"(r1)) NINT_VMCASE(6, "+v"(r0), "+v"(r1)) NINT_VMCASE(7, "+v"(r0), "+v"(r1)) NINT_VMCASE(8, "+v"(r0), "+v"(r1))
-    NINT_VMCASE(9, "+v"(r0), "+v"(r1)) NINT_VMCASE(10, "+v"(r0), "+v"(r1))
-    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1) : : "memory"); break;
-  }
-}
-#undef NINT_VMCASE
-__device__ __forceinline__ void wait_vm_rt(int n) {       // wave-uniform run-time count: a scalar branch to the matching immediate
-  switch (n) {
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-}
 template <int N> __device__ __forceinline__ void wait_vm() {
-  if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else static_assert(N < 0, "add the immediate");
+  static_assert(N >= 0 && N <= 12, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
@@ -190,20 +138,13 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int PS, int D, int R, int KS, bool WREG>
+template <int PS, int D, int R, int KS>
 __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
   constexpr int CG = 8 / PS, RPW = 8, NTW = 4;       // 8 row tiles x 4 column tiles per wave: 128 accumulator registers
   constexpr int k = KS, taps = KS * KS, p = KS / 2;
   constexpr int WT_BYTES = 4 * CG * 1024;            // weight tile of one K-step
   constexpr int PPWB = CG >= 2 ? CG / 2 : 1;         // weight pieces per wave per K-step (CG = 1: waves 0-3 only)
-  // WREG: the weight tile goes global -> registers -> LDS (plain loads two K-steps ahead into two register sets, ds_write one
-  // step ahead into a 2-slot ring) instead of by LDS-DMA into a D-slot ring.  Measured (tools/wideprobe.py): an LDS-DMA piece
-  // costs its issuing wave ~190 cycles here -- 17 pieces per K-step and CU made P1 570 cycles long against the 512 of the
-  // other group's MFMAs -- while the 4-wave kernel shows that plain 1-KiB fragment loads at twice this rate issue freely.
-  // WREG ring: THREE slots.  The fragment reads of P1 stay in flight across the barrier (they are consumed by the MFMAs of P2),
-  // so when group 0 writes step s+1 in P1(s), group 1's reads of step s-1 may still be pending: with two slots that is the
-  // slot being written (a rare wrong tile, found as a NaN after a few hundred launches); with three it is another one.
-  static_assert(WREG ? D == 3 : D >= 4, "DMA ring: group 1 waits D-3 steps ahead; register staging: three slots");
+  static_assert(D >= 4, "group 1 waits D-3 steps ahead");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,8 +154,8 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
   const unsigned wring = lds0 + R * chunk_bytes;
   const int nchunks = a.nchunk0 + a.nchunk1, spt = a.spt;
 
-  // ---- this workgroup's tiles.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one L2), so XCD x
-  // takes the contiguous tile range x and its workgroups walk it with the stride of their number: tiles that are
+  // ---- this workgroup's units.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one L2), so XCD x
+  // takes the contiguous unit range x and its workgroups walk it with the stride of their number: tiles that are
   // neighbours in space (shared halo pixels, the same images) are neighbours in time on one L2.  Any bijection is correct.
   int t_first, t_cnt, t_stride;
   {
@@ -234,43 +175,30 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
   int nt0;                                            // first n-tile of this wave in the unit being computed
 
   // ---- DMA issue ------------------------------------------------------------------------------------------------
-  // All per-step bookkeeping is INCREMENTAL scalar state (no division, no multiplication, no kernel-argument reload in the
-  // K loop): the whole of P1 must fit under the 512 cycles of the other wave group's MFMAs.
   // weights: piece j of K-step ws of column-group set ch comes from Bp + ((ws * NTt + ch * 4 * CG + j) << 10), lane-linear on both sides
-  const char* Bw_lane_reg = a.Bp + (size_t)(wave * PPWB) * 1024 + lane * 16;   // (WREG) this wave's first piece of step 0, set 0
   const unsigned bstep = (unsigned)a.NTt * 1024;
   const int ny = a.ny;
   int w_ch = t_first % ny;                            // column-group set of the unit whose weights are being fetched
   const int w_chstep = t_stride % ny;                 // ... and how it moves from one of this workgroup's units to the next
-  // K order: chunk by chunk, and inside a chunk the k*k taps CYCLICALLY from this workgroup's own first tap t0.  In plain
-  // order all 256 persistent workgroups walk the packed weights in lockstep, i.e. every CU of an XCD asks its L2 for the
-  // same 16 KiB at the same moment, step after step; rotated, the requests of a moment spread over k*k weight tiles.
-  // (f32 accumulation order, hence the last bits, then depend on the workgroup: deterministic for a given launch shape.)
+  // K order: chunk by chunk, and inside a chunk the k*k taps CYCLICALLY from this workgroup's own first tap t0 (a.rot).  In
+  // plain order all persistent workgroups walk the packed weights in lockstep, i.e. every CU of an XCD asks its L2 for the
+  // same tile at the same moment, step after step; rotated, the requests of a moment spread over k*k weight tiles
+  // (measured: no gain, 2186-2387 vs 2377 cycles per K-step; results then differ from the plain order in the last bits).
   const int t0 = a.rot ? (int)(blockIdx.x % taps) : 0;
   const int ty0 = t0 / k, tx0 = t0 - ty0 * k;
   unsigned w_off = (unsigned)w_ch * WT_BYTES + (unsigned)t0 * bstep;   // byte offset of the next step to issue inside the packed weights
   int w_left = S;                                     // steps not yet issued
   int w_ws = 0;                                       // ... its index inside its unit
   int w_tapi = t0, w_cnt = 0;                         // ... its tap, and how many steps of its chunk period have been issued
-  // DMA roles (DMA ring): vmcnt retires in order, so a wave that has issued a long-latency halo piece (HBM / MALL) cannot
-  // confirm a younger weight piece before it -- measured: the ~1.2 halo pieces per K-step and CU cost as much K-loop time
-  // as the 16 weight pieces.  So the halo pieces are issued by waves 3 and 7 (one per group) ALONE, which wait for them once
-  // per chunk period, and the weight pieces by the other six waves, whose counted waits then only ever see L2-latency pieces.
-#ifdef WIDE_ROLE_SPLIT     // experiment: halo pieces by waves 3 / 7 alone, weight pieces by the other six (measured slower: 2586 vs ~1950 cycles per K-step)
-  const bool chunk_wave = !WREG && (wave & 3) == 3;
-  const int wi = wave - (wave >> 2);                  // 0..5 among the weight issuers (waves 0,1,2,4,5,6)
-  constexpr int NPW = 4 * CG, WBASE = NPW / 6, WREM = NPW % 6;
-  const int w_cnt_pieces = WREG ? PPWB : (chunk_wave ? 0 : WBASE + (wi < WREM ? 1 : 0));       // weight pieces this wave issues per K-step
-  const int w_first = WREG ? wave * PPWB : wi * WBASE + (wi < WREM ? wi : WREM);
-#else
-  constexpr bool chunk_wave = false;
-  const int w_cnt_pieces = (CG == 1 && wave >= 4) ? 0 : PPWB;
-  const int w_first = wave * PPWB;
-#endif
-  unsigned w_lds = wring + (unsigned)w_first * 1024;  // LDS address of this wave's first piece in the next ring slot
+  const bool w_issuer = !(CG == 1 && wave >= 4);
+  const char* Bw_lane = a.Bp + (size_t)(wave * PPWB) * 1024 + lane * 16;   // this wave's first piece of step 0, set 0
+  unsigned w_lds = wring + (unsigned)(wave * PPWB) * 1024;                 // LDS address of that piece in the next ring slot
   int w_slot = 0;
-  u32x4_t wr[2][PPWB];                                // WREG: the two register sets (K-steps of equal parity share one)
-  auto advance_weights = [&]() __attribute__((always_inline)) {
+  auto issue_weights = [&]() __attribute__((always_inline)) {
+    if (w_issuer) {
+      if constexpr (PPWB == 2) glds16x2(Bw_lane + w_off, w_lds);
+      else glds16(Bw_lane + w_off, w_lds);
+    }
     --w_left;
     w_off += bstep; ++w_ws; ++w_tapi; ++w_cnt;
     if (w_tapi == taps) { w_tapi = 0; w_off -= taps * bstep; }        // tap k*k-1 -> tap 0 of the same chunk
@@ -281,38 +209,6 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
       if (w_ch >= ny) w_ch -= ny;
       w_off = (unsigned)w_ch * WT_BYTES + (unsigned)t0 * bstep;
     }
-  };
-  auto load_weights = [&](auto par) __attribute__((always_inline)) {          // next step's pieces -> register set `par`
-    if (!(CG == 1 && wave >= 4)) {
-#pragma unroll
-      for (int i = 0; i < PPWB; ++i) gload16_asm(wr[decltype(par)::value][i], Bw_lane_reg + w_off + i * 1024);
-    }
-    advance_weights();
-  };
-  // register set `par` -> ring slot.  younger = the vector-memory operations this wave has issued SINCE the set's loads (the
-  // other set's loads, DMA pieces): exactly those may still be in flight (vmcnt retires in order).  An over-count would let the
-  // set's own loads be in flight at the ds_write -- it was one, at the end of a run, where no further loads follow: a rare wrong
-  // column group in the last K-step --; an under-count only waits longer (compiler-issued loads / stores are not counted).
-  auto store_weights = [&](auto par, int slot, int younger) __attribute__((always_inline)) {
-    if (!(CG == 1 && wave >= 4)) {
-      if constexpr (PPWB == 2) wait_vm_regs_rt(younger, wr[decltype(par)::value][0], wr[decltype(par)::value][1]);
-      else wait_vm_regs_rt(younger, wr[decltype(par)::value][0]);
-      char* dst = smem + R * chunk_bytes + slot * WT_BYTES + (wave * PPWB) * 1024 + lane * 16;
-#pragma unroll
-      for (int i = 0; i < PPWB; ++i) *(u32x4_t*)(dst + i * 1024) = wr[decltype(par)::value][i];
-    }
-  };
-  auto issue_weights = [&]() __attribute__((always_inline)) {
-    const char* src = a.Bp + lane * 16 + (size_t)w_first * 1024 + w_off;
-#ifdef WIDE_ROLE_SPLIT
-    for (int i = 0; i < w_cnt_pieces; ++i) glds16(src + i * 1024, w_lds + i * 1024);
-#else
-    if (w_cnt_pieces) {
-      if constexpr (PPWB == 2) glds16x2(src, w_lds);
-      else glds16(src, w_lds);
-    }
-#endif
-    advance_weights();
     w_lds += WT_BYTES; ++w_slot;
     if (w_slot == D) { w_slot = 0; w_lds -= D * WT_BYTES; }
   };
@@ -338,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
     glds16(f_base + off + g * 16, f_lds + q * 1024);
   };
 
-  // chunk-fetch cursor: tile d_j, chunk d_c of it
+  // chunk-fetch cursor: unit d_j, chunk d_c of it
   int d_c = 0, d_j = 0;
   WTile d_tile = wide_tile(a, t_first);
   auto set_fetch = [&]() __attribute__((always_inline)) {
@@ -360,23 +256,12 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
     if (d_j < t_cnt) set_fetch();
   };
 
-  // ---- prologue: chunks 0 .. R-2 whole, weights of steps 0 .. D-2; the only full drain of the run
+  // ---- prologue: chunks 0 .. R-2 whole, weights of steps 0 .. D-2; one full drain
   for (int r = 0; r < R - 1 && d_j < t_cnt; ++r) {
-    for (int q = wave; q < npc; q += 8) issue_chunk_piece(q);       // (the prologue: all eight waves, one drain)
+    for (int q = wave; q < npc; q += 8) issue_chunk_piece(q);
     advance_chunk_cursor();
   }
-  typedef std::integral_constant<int, 0> P0;
-  typedef std::integral_constant<int, 1> P1_;
-  if constexpr (WREG) {
-    // step 0 -> slot 0 now; step 1 -> set 1 (written in P1(0)); step 2 -> set 0 (written in P1(1))
-    load_weights(P0{});
-    store_weights(P0{}, 0, 0);
-    if (w_left > 0) load_weights(P1_{});
-    if (w_left > 0) load_weights(P0{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  } else {
-    for (int i = 0; i < D - 1 && w_left > 0; ++i) issue_weights();
-  }
+  for (int i = 0; i < D - 1 && w_left > 0; ++i) issue_weights();
   wait_vm<0>();
   wg_barrier();
   if (grp == 1) wg_barrier();                         // the second wave of every SIMD runs one barrier behind the first
@@ -420,67 +305,18 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
 
   WSTAMP1(st_loop0)
   WACC1(6, st_t0, st_loop0)
-  int s = 0;
-  int vm_np2 = 0, vm_np1 = 0, vm_nl1 = 0;             // WREG: DMA pieces / weight loads this wave issued two steps / one step ago
-  // one K-step; `par` = s & 1 as a type (WREG: it names the register set / ring slot of the step, statically)
-  auto step = [&](auto par) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(par)::value;
-    typedef std::integral_constant<int, 1 - PAR> Other;
+  for (int s = 0; s < S; ++s) {
     WSTAMP(st_a)
     // ============================== P1(s): DMA issue, fragment reads ==============================
     // pieces of the chunk R-1 periods ahead (fetch cursor) during the first steps of this chunk period, ahead of the weights
-    auto issue_dma = [&]() __attribute__((always_inline)) {
-      int nl0 = 0, np0 = 0;                          // loads / DMA pieces this wave issues in this step
-      if constexpr (WREG) {
-        // weights of step s+1 (loaded two steps ago into the other register set) -> the next ring slot: its last readers
-        // (group 1, P1(s-2)) are two barriers behind; then that set takes step s+3.  Issued since those loads: the pieces of
-        // that step, and the loads and pieces of the step in between.
-        if (s + 1 < S) store_weights(Other{}, b_slot == D - 1 ? 0 : b_slot + 1, vm_np2 + vm_nl1 + vm_np1);
-        if (w_left > 0) { load_weights(Other{}); nl0 = (CG == 1 && wave >= 4) ? 0 : PPWB; }
+    if (d_j < t_cnt) {
+      for (int e = 0; e < pps; ++e) {
+        const int q = wave + 8 * (c_tap * pps + e);
+        if (q < npc) issue_chunk_piece(q);
       }
-#ifndef WIDE_ABL_NOCHUNK
-      if (d_j < t_cnt) {
-        if constexpr (WREG) {
-          for (int e = 0; e < pps; ++e) {
-            const int q = wave + 8 * (c_tap * pps + e);
-            if (q < npc) { issue_chunk_piece(q); ++np0; }
-          }
-        }
-#ifdef WIDE_ROLE_SPLIT
-        else if (chunk_wave) {                       // waves 3 / 7 take the even / odd pieces, pps of them per step
-          for (int e = 0; e < pps; ++e) {
-            const int q = 2 * (c_tap * pps + e) + (wave >> 2);
-            if (q < npc) issue_chunk_piece(q);
-          }
-        }
-#else
-        else {
-          for (int e = 0; e < pps; ++e) {
-            const int q = wave + 8 * (c_tap * pps + e);
-            if (q < npc) issue_chunk_piece(q);
-          }
-        }
-#endif
-      }
-#endif
-      if constexpr (!WREG) {
-#ifdef WIDE_ABL_NOWEIGHTS
-        if (w_left > 0) { --w_left; }
-#else
-        if (w_left > 0) issue_weights();
-#endif
-      }
-      vm_np2 = vm_np1; vm_np1 = np0; vm_nl1 = nl0;
-    };
-#if !defined(WIDE_DMA_IN_P2) && !defined(WIDE_ABL_NODMA)
-    issue_dma();
-#endif
-    WSTAMP(st_a1)
-    WACC(8, st_a, st_a1)
+    }
+    if (w_left > 0) issue_weights();
     u32x4_t bq[NTW], ax[RPW];
-#ifdef WIDE_ABL_NOREADS
-    if (s == 0)
-#endif
     {
       const char* Bs = smem + b_soff + blane;
 #pragma unroll
@@ -488,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
 #pragma unroll
       for (int i = 0; i < RPW; ++i) ax[i] = *(const u32x4_t*)(smem + (a_soff + arow[i]));
     }
-    const bool last = c_ws + 1 == spt;                // last K-step of the tile
+    const bool last = c_ws + 1 == spt;                // last K-step of the unit
     if (last) {                                       // c_{t-1} of the tile's rows, one K-step ahead of the epilogue
       if (a.c_prev) {                                 // (branch-free per row: pixels outside the grid read pixel (0, 0) of the image)
 #pragma unroll
@@ -504,57 +340,29 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
         for (int i = 0; i < RPW; ++i) cpv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       }
     }
-    WSTAMP(st_a2)
-    WACC(9, st_a1, st_a2)
-    // this wave's ds_write of step s+1 is in LDS before the barrier: the RPW + NTW fragment reads behind it may stay in flight
-    // (LDS operations complete in order; SMEM loads, which share the counter, can only complete earlier)
-    if constexpr (WREG) asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(RPW + NTW) : "memory");
     WSTAMP(st_b)
     wg_barrier();
     WSTAMP(st_c)
     // ============================== P2(s): MFMAs, counted wait ==============================
-    constexpr int MG = RPW >= 4 ? 4 : RPW;            // row groups
-    constexpr int RG = RPW / MG;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int gq = 0; gq < MG; ++gq) {
+    for (int i = 0; i < RPW; ++i)
 #pragma unroll
-      for (int r = 0; r < RG; ++r)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-          acc[gq * RG + r][j] = mma_step<NINT_BF16>(bq[j], ax[gq * RG + r], acc[gq * RG + r][j]);   // swapped: D[channel][pixel]
-#ifdef WIDE_DMA_IN_P2
-      // (measured: the pieces' issue cost does NOT hide between the MFMAs -- 547 -> 1004 cycles for the MFMA phase -- so the
-      // product issues them in P1, beside the other wave group's matrix work)
-      __builtin_amdgcn_sched_barrier(0);
-      if (gq == 1) issue_dma();
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
+      for (int j = 0; j < NTW; ++j) acc[i][j] = mma_step<NINT_BF16>(bq[j], ax[i], acc[i][j]);   // swapped: D[channel][pixel]
     __builtin_amdgcn_s_setprio(0);
     WSTAMP(st_d)
-    // weights of step s+1 (group 0) / s+2 (group 1) have landed for this wave; near the end of the run fewer steps are in flight
-    if constexpr (WREG) {
-      // the weight loads are the compiler's (it waits before the ds_write); the asm DMA pieces of the chunk being fetched are
-      // older than this step's loads: at the end of every chunk period wait for everything but those loads
-      // (two steps before the period's end: group 1 runs one barrier behind, and with R = 2 the chunk is read in the very next period)
-      if (c_tap == taps - 2) { if (vm_nl1) wait_vm<PPWB>(); else wait_vm<0>(); }
-    } else {
-      // The counted wait is exact only among operations of ONE kind: the register-staged experiment (WREG) showed that an
-      // LDS-DMA piece can complete, and decrement vmcnt, before an OLDER plain load.  Around a unit's end this wave also has
-      // plain loads (c_{t-1}, the next unit's bias) and the epilogue's stores in flight, so there -- the unit's last step and
-      // the D steps behind the epilogue -- and at the end of the run the wait is a full drain.
-      if (chunk_wave) { if (c_tap == taps - 2) wait_vm<0>(); }      // its halo pieces of this period (issued in its first steps)
-      else if (s + D >= S || last || (c_j > 0 && c_ws < D)) wait_vm<0>();
-      else wait_vm_rt((grp == 0 ? D - 2 : D - 3) * w_cnt_pieces);
-    }
+    // weights of step s+1 (group 0) / s+2 (group 1) have landed for this wave; a full drain where other kinds of operations
+    // are in flight (header) and near the end of the run
+    if (s + D >= S || last || (c_j > 0 && c_ws < D) || !w_issuer) wait_vm<0>();
+    else if (grp == 0) wait_vm<(D - 2) * PPWB>();
+    else wait_vm<(D - 3) * PPWB>();
     WSTAMP(st_e)
     wg_barrier();
     WSTAMP(st_f)
     WACC(0, st_a, st_b) WACC(1, st_b, st_c) WACC(2, st_c, st_d) WACC(3, st_d, st_e) WACC(4, st_e, st_f)
 
     // ============================== advance the cursors ==============================
-    ++c_ws; ++s;
+    ++c_ws;
     b_soff += WT_BYTES; ++b_slot;
     if (b_slot == D) { b_slot = 0; b_soff -= D * WT_BYTES; }
     a_soff += 16; ++txx;
@@ -615,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
           }
         }
       }
-      // ---------------------------------------------------------------- next tile
+      // ---------------------------------------------------------------- next unit
       c_ws = 0;
       if (++c_j < t_cnt) {
         ct = wide_tile(a, t_first + c_j * t_stride);
@@ -627,12 +435,8 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
       WACC1(5, st_ep0, st_g)
     }
     if (new_period) a_soff = a_slot * chunk_bytes + (ty0 * HWtc + tx0) * 16;   // (after a unit switch: the new tile's halo width)
-  };
-  while (s < S) {
-    step(P0{});
-    if (s < S) step(P1_{});
   }
-  if (grp == 0) wg_barrier();
+  if (grp == 0) wg_barrier();                         // pairs with group 1's extra barrier at the start
 #ifdef NINT_STAMP
   if (lane == 0 && blockIdx.x < WIDE_STAMP_WGS) {
     unsigned long long* o = g_wide_stamp + ((size_t)blockIdx.x * 8 + wave) * 16;
@@ -646,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
 // ------------------------------------------------------------------------------ host side
 static unsigned magic_of(int d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
 
-template <int PS, int D, int KS, bool WREG>
+template <int PS, int D, int KS>
 static int launch_wide(WideArgs& a, int n_cu, int R, hipStream_t st) {
   constexpr int CG = 8 / PS;
   const size_t lds = (size_t)R * a.nhpp * 64 + (size_t)D * 4 * CG * 1024;
@@ -654,9 +458,9 @@ static int launch_wide(WideArgs& a, int n_cu, int R, hipStream_t st) {
   const int nwg = a.nunits < n_cu ? a.nunits : n_cu;
 #define NINT_WIDE_LAUNCH(R_)                                                                                          \
   {                                                                                                                   \
-    auto kern = conv_wide_lstm_kernel<PS, D, R_, KS, WREG>;                                                                     \
+    auto kern = conv_wide_lstm_kernel<PS, D, R_, KS>;                                                                 \
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, st, a);                                                   \
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, st, a);                                                       \
   }
   if (R == 2) NINT_WIDE_LAUNCH(2) else if (R == 3) NINT_WIDE_LAUNCH(3) else if (R == 4) NINT_WIDE_LAUNCH(4) else return NINT_E_ARG;
 #undef NINT_WIDE_LAUNCH
@@ -665,7 +469,7 @@ static int launch_wide(WideArgs& a, int n_cu, int R, hipStream_t st) {
 }
 
 // Plan of one tile size (PS pixel slices of 8 row tiles: 256 or 512 pixels per workgroup tile, 64*8/PS gate columns per unit).
-template <int PS, int D, bool WREG>
+template <int PS, int D>
 static int plan_wide(WideArgs& a, int N, int* R_out) {
   constexpr int CG = 8 / PS, TRT = PS * 8;
   if (a.NTt % (4 * CG)) return NINT_E_SHAPE;
@@ -712,49 +516,32 @@ static int plan_wide(WideArgs& a, int N, int* R_out) {
   a.magic_nhpp = magic_of(a.nhpp);
   a.npc = a.nhpp / 16;
   a.spt = (a.nchunk0 + a.nchunk1) * a.taps;
-  // chunk ring depth and issue rate.  DMA weight ring: the pieces of chunk g+R-1 go out during the first steps of period g
-  // and must be older than every weight piece waited for at the start of period g+R-1 (header comment): last issue step
-  // <= (R-1)*taps - D.  Register-staged weights: the pieces are waited for two steps before the end of the period they are issued in.
-  // (DMA ring: two waves issue the pieces of a chunk and wait for them two steps before the end of the period they are issued in)
-#ifdef WIDE_ROLE_SPLIT
-  const int wave_pieces = nint_cdiv(a.npc, WREG ? 8 : 2);
-#else
+  // chunk ring depth and issue rate: the pieces of chunk g+R-1 go out during the first steps of period g and must be older
+  // than every weight piece waited for at the start of period g+R-1 (header comment): last issue step <= (R-1)*taps - D
   const int wave_pieces = nint_cdiv(a.npc, 8);
-#endif
   for (int r = 2; r <= 4; ++r) {
-#ifndef WIDE_PPS_MIN
-#define WIDE_PPS_MIN 1
-#endif
-    for (int pps = (WIDE_PPS_MIN < wave_pieces ? WIDE_PPS_MIN : wave_pieces); pps <= 8; ++pps) {
+    for (int pps = 1; pps <= 8; ++pps) {
       const int issue_steps = nint_cdiv(wave_pieces, pps);
-#ifdef WIDE_ROLE_SPLIT
-      const bool in_time = issue_steps <= a.taps - 2;
-#else
-      const bool in_time = WREG ? issue_steps <= a.taps - 2 : (issue_steps <= a.taps && issue_steps - 1 <= (r - 1) * a.taps - D);
-#endif
+      const bool in_time = issue_steps <= a.taps && issue_steps - 1 <= (r - 1) * a.taps - D;
       if (in_time && (size_t)r * a.nhpp * 64 + (size_t)D * 4 * CG * 1024 <= 160 * 1024) { *R_out = r; a.pps = pps; return NINT_OK; }
     }
   }
   return NINT_E_LDS;
 }
 
-// Serves: bf16, LSTM epilogue, k x k taps on both sources (no horizontal fold), k = 3 or 5, gate columns a multiple of 128,
-// enough tiles to give every CU one.  NINT_E_SHAPE = not served (the caller takes conv_igemm.hip's kernel).
-// force: 0 = only where it is expected to win; 2 = wherever it is instantiated; 3 / 4 = that, with 256- / 512-pixel tiles;
-// + 8 = taps in plain order in every workgroup (results then equal the 4-wave kernel's bit for bit).
+// Serves: bf16, LSTM epilogue, k x k taps on both sources (no horizontal fold), k = 3 or 5, gate columns a multiple of 128.
+// NINT_E_SHAPE = not served (the caller takes conv_igemm.hip's kernel).
+// force (nint_layer.wide): 0 = the library's choice -- never this kernel, see below; 2 = wherever it is instantiated; 3 / 4 = that,
+// with 256- / 512-pixel tiles; + 8 = taps in plain order in every workgroup (results then equal the 4-wave kernel's bit for bit).
 int nint_internal_conv_wide_lstm(const ConvArgs& c, int N, int force_, void* stream) {
-  const int force = force_ & 7, rot = (force_ & 8) ? 0 : 1;      // + 8: plain K order (bit-identical to the 4-wave kernel: tests)
+  const int force = force_ & 7, rot = (force_ & 8) ? 0 : 1;
+  // Measured on MI355X at the bench shape (B = 8, 100 x 154, 62 + 64 -> 256, k = 5): 187-200 us per launch in the step against
+  // 167-171 us for the 4-wave kernel -- the K loop runs ~1950 cycles per K-step instead of the ~1000 it reaches with the DMA
+  // issue ablated (an LDS-DMA piece costs its issuing wave ~200 cycles, a halo gather piece far more, and the
+  // barrier-coupled loop makes all eight waves wait for it).
+  if (!force) return NINT_E_SHAPE;
   if (c.kx0 != c.k || (c.k != 3 && c.k != 5) || c.nchunk0 + c.nchunk1 < 1) return NINT_E_SHAPE;
-#ifdef WIDE_WREG
-  constexpr bool WREG = true;                      // A/B build: weights through registers into a 3-slot ring
-  constexpr int D = 3;
-#else
-  constexpr bool WREG = false;
-#ifndef WIDE_D
-#define WIDE_D 5
-#endif
-  constexpr int D = WIDE_D;
-#endif
+  constexpr int D = 5;
   int dev = 0, n_cu = 0;
   NINT_CHECK_HIP(hipGetDevice(&dev));
   NINT_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -765,23 +552,18 @@ int nint_internal_conv_wide_lstm(const ConvArgs& c, int N, int force_, void* str
   a.H = c.H; a.W = c.W; a.P = c.P; a.Hh = c.Hh; a.Wh = c.Wh;
   a.bias = c.bias; a.c_prev = c.c_prev; a.c_out = c.c_out; a.h_out = c.h_out; a.gates_out = c.gates_out;
   a.Chp = c.Chp; a.Ch16 = c.Ch16;
-  // 512-pixel tiles (half the weight bytes per MFMA: the L2 -> CU path, not the matrix pipe, paces the 256-pixel version) when
-  // their units fill the CUs about as evenly as the 256-pixel ones; efficiency = units / (rounds * CUs)
+  // 512-pixel tiles (half the weight bytes per MFMA) when their units fill the CUs about as evenly as the 256-pixel ones;
+  // efficiency = units / (rounds * CUs)
   WideArgs a4 = a, a2 = a;
   int R4 = 0, R2 = 0;
-  const int rc4 = force == 3 ? NINT_E_SHAPE : plan_wide<4, D, WREG>(a4, N, &R4);
-  const int rc2 = force == 4 ? NINT_E_SHAPE : plan_wide<2, D, WREG>(a2, N, &R2);
+  const int rc4 = force == 3 ? NINT_E_SHAPE : plan_wide<4, D>(a4, N, &R4);
+  const int rc2 = force == 4 ? NINT_E_SHAPE : plan_wide<2, D>(a2, N, &R2);
   auto eff = [&](const WideArgs& w) { return (double)w.nunits / ((double)nint_cdiv(w.nunits, n_cu) * n_cu); };
   const bool use4 = rc4 == NINT_OK && (rc2 != NINT_OK || eff(a4) >= 0.9 * eff(a2));
   if (!use4 && rc2 != NINT_OK) return NINT_E_SHAPE;
   WideArgs& w = use4 ? a4 : a2;
   w.rot = rot;
-  // force == 0 (nint_layer.wide = 0): NOT taken.  Measured on MI355X at the bench shape (B = 8, 100 x 154, 62 + 64 -> 256, k = 5):
-  // 187-200 us per launch in the step against 171 us for the 4-wave kernel -- the K loop runs ~1950 cycles per K-step instead
-  // of the ~1050 it reaches with the DMA issue ablated (an LDS-DMA piece costs its issuing wave ~220 cycles, a
-  // halo gather piece far more); kept for nint_layer.wide >= 2 (tests, tools/wideprobe.py, the ablation record).
-  if (!force) return NINT_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (use4) return a.k == 5 ? launch_wide<4, D, 5, WREG>(w, n_cu, R4, st) : launch_wide<4, D, 3, WREG>(w, n_cu, R4, st);
-  return a.k == 5 ? launch_wide<2, D, 5, WREG>(w, n_cu, R2, st) : launch_wide<2, D, 3, WREG>(w, n_cu, R2, st);
+  if (use4) return a.k == 5 ? launch_wide<4, D, 5>(w, n_cu, R4, st) : launch_wide<4, D, 3>(w, n_cu, R4, st);
+  return a.k == 5 ? launch_wide<2, D, 5>(w, n_cu, R2, st) : launch_wide<2, D, 3>(w, n_cu, R2, st);
 }
