@@ -64,11 +64,13 @@ typedef struct nint_layer {
                            * kx*Cx + c holds x[.., x + kx - k/2][c] (0 outside the image), Cxp = roundup(k*Cx, KC), and
                            * the x part of K is k vertical taps x k*Cx channels instead of k*k taps x Cx channels padded
                            * to KC each (reference layer 0: Conv2d(5+64 -> 256, k=5), model.py:207-211: 5 x-steps, not 25) */
-  int32_t wide;           /* gate / dgrad kernel family: 0 = chosen per launch shape; 1 = always the 4-wave kernels whose waves
-                           * stream their own weight fragments from L2 (csrc/conv_igemm.hip); 2 = the 8-wave kernel that stages
-                           * each K-step's weight tile ONCE per workgroup in LDS (csrc/conv_wide.hip) wherever it is
-                           * instantiated (bf16, gate columns a multiple of 128, k = 3 or 5); 3 / 4 = that, with its 256- / 512-pixel
-                           * tiles forced (tests).  Same arithmetic, same summation order per output. */
+  int32_t wide;           /* gate kernel family: 0 = the library's choice (the 4-wave kernels, whose waves stream their own weight
+                           * fragments from L2: csrc/conv_igemm.hip); 1 = the same, explicitly; 2 = the persistent 8-wave kernel that
+                           * stages each K-step's weight tile ONCE per workgroup in LDS (csrc/conv_wide.hip) wherever it is
+                           * instantiated (bf16, gate columns a multiple of 128, k = 3 or 5, unfolded input) -- measured slower,
+                           * kept opt-in; 3 / 4 = that, with its 256- / 512-pixel tiles forced; + 8 = its taps in
+                           * plain order in every workgroup: results then equal the 4-wave kernel's bit for bit (without: every
+                           * workgroup starts a chunk's taps at its own tap, i.e. another f32 summation order) */
   const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */
   const void* Wd;         /* dgrad weights (transposed + flipped), ET */
   const float* bias_p;    /* bias permuted to gate-stash column order [4*Ch16] */

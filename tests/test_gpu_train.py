@@ -309,6 +309,43 @@ def test_bench_under_torchrun_with_rccl_group(pkg):
     assert ph["gate0"]["launches"] == 12 and ph["wgrad0"]["launches"] == 1 and 0 < d["phases"]["probe_pair_cost_us"] < 50
 
 
+def test_timing_probes_bracket_every_launch_and_change_nothing(pkg):
+    """nint_seq.probe (how bench.py prices kernels inside the step): stamp launches around the selected launches of
+    nint_seq_fwd / nint_seq_bwd.  They must not change a bit of the step's results, every (kind, layer, t) must appear as a
+    begin / end pair in launch order with non-decreasing timestamps, and a step without probes must leave the buffer alone."""
+    import bench
+    from nasa_niswan_amd.trainer import FusedTrainer
+    from oracle import convlstm_oracle as O
+    C_, hidden, ks, B, T, H, W = 5, [16, 8, 8], [5, 3, 3], 2, 4, 20, 28
+    params = O.synth_params(C_, hidden, ks, 3, seed=3)
+    X, y = O.synth_batch(B, T, C_, H, W, (10, 18), seed=3)
+    res = {}
+    for probed in (False, True):
+        net = pkg.ConvLSTM(C_, hidden, ks, 3, compute_dtype="bf16").cuda()
+        net.load_state_dict(params)
+        tr = FusedTrainer(net, lr=1e-3, halo=(5, 5))
+        buf = torch.zeros(2 * 1024, dtype=torch.int64, device="cuda")
+        if probed:
+            tr.set_probe(buf, 0x7e)                  # every kind
+        loss = float(tr.step(X.cuda(), y.cuda()))
+        torch.cuda.synchronize()
+        res[probed] = (loss, tr.flat.grad.clone(), tr.flat.data.clone(), buf.cpu().numpy())
+    assert res[False][0] == res[True][0] and torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+    assert not res[False][3].any()
+    w = res[True][3]
+    fwd, bwd = bench.probe_table(w[:1024]), bench.probe_table(w[1024:])
+    assert [r[:4] for r in fwd[:2]] == [(0, 0, 0, 0), (0, 0, 0, 1)] and [r[:4] for r in bwd[:2]] == [(0, 0, 0, 0), (0, 0, 0, 1)]
+    gates = [(r[1], r[2], r[3]) for r in fwd[2:]]
+    assert gates == [(l, t, e) for t in range(T) for l in range(3) for e in (0, 1)] and all(r[0] == 1 for r in fwd[2:])
+    for tab in (fwd, bwd):
+        ticks = [r[4] for r in tab]
+        assert all(b >= a for a, b in zip(ticks, ticks[1:])) and ticks[-1] > ticks[0]
+    kinds = {r[0] for r in bwd[2:]}
+    assert {2, 3, 5, 6} <= kinds                      # pointwise, dgrad, weight gradients, fold (the fused step: kind 4, per schedule)
+    d = bench.probe_durations(w[:1024], w[1024:])
+    assert len(d[(1, 0)]) == T and all(us > 0 for _, us in d[(1, 0)]) and len(d[(5, 0)]) == 1
+
+
 def test_bench_starts_its_own_ranks(pkg):
     """`python bench.py --gpus 1 --force-dist` is what the driver runs for N = 1; for N > 1 the same form must start N
     ranks by itself.  On this one-GPU box: the parent decides from argv, the torchrun child runs the single rank."""

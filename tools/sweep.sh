@@ -3,8 +3,10 @@
 # usage: tools/sweep.sh <out.jsonl>     (on the GPU box; ~2 minutes)
 OUT=${1:-gpurun_out/sweep.jsonl}
 : > "$OUT"
-run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> "$OUT"; }
+run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --long-steps 0 "$@" 2>/dev/null | tail -1 >> "$OUT"; }
 run --batch 1
+run --batch 2
+run --batch 4
 run --batch 8
 run --batch 32
 run --batch 8 --dtype f32
