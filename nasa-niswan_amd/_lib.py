@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libnint_hip.so")     # the one product library; n
 NINT_F32, NINT_BF16 = 0, 1
 NINT_OK, NINT_E_ARG, NINT_E_SHAPE, NINT_E_LDS, NINT_E_ALIGN = 0, -1, -2, -3, -4
 NINT_MAX_LAYERS = 8
-NINT_VERSION = 107     # include/nint.h NINT_VERSION: the library this binding was written against
+NINT_VERSION = 108     # include/nint.h NINT_VERSION: the library this binding was written against
 NINT_LOSS_SCRATCH_FLOATS = 8194
 NINT_LOSS_STATS = 8
 
@@ -38,7 +38,8 @@ class NintSeq(C.Structure):
                 ("gates", vp * NINT_MAX_LAYERS), ("dG", vp * NINT_MAX_LAYERS), ("dh", vp * NINT_MAX_LAYERS),
                 ("dc", vp * NINT_MAX_LAYERS), ("dx", vp), ("dW", vp * NINT_MAX_LAYERS), ("db", vp * NINT_MAX_LAYERS),
                 ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t), ("fuse_bwd", C.c_int32),
-                ("probe_mask", C.c_int32), ("probe", vp), ("probe_slots", C.c_int32)]
+                ("probe_mask", C.c_int32), ("probe", vp), ("probe_slots", C.c_int32),
+                ("wave", C.c_int32), ("wave_stream", vp * NINT_MAX_LAYERS), ("wave_event", vp * (NINT_MAX_LAYERS + 1))]
 
 
 # every symbol include/nint.h declares: name -> (restype, argtypes)

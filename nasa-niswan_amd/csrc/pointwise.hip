@@ -670,34 +670,46 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const void* __restrict
   }
 }
 
-// Fast path for small heads (O*(Ch+1) <= 512 outputs): every workgroup owns a pixel range, stages HEAD_DW_PIX pixels of
-// dpred and h in LDS at a time (ONE HBM round trip per 240 pixels: the launch is latency-bound, 14 MB in all), thread
-// (o, c) accumulates its own output over the range; per-workgroup partials are folded in fixed order by
+// Tiled path (O*(Ch+1) <= HEAD_DW_NK*512 outputs): every workgroup owns a pixel range, stages `stage` pixels of dpred and
+// h in LDS at a time (ONE HBM round trip per stage: the launch is latency-bound, 14 MB in all for the bench's head), thread
+// i accumulates the outputs i, i+512, ... over the range; per-workgroup partials are folded in fixed order by
 // head_bwd_dw_final_kernel.  The grid is one workgroup per HEAD_DW_PIX pixels, as far as the caller's scratch goes.
+// (Wide heads -- 128 hidden channels, or 200 outputs -- used to fall to head_bwd_dw_kernel: one workgroup per output walking
+// every pixel with a 4-byte strided read, 2.5 ms per step for configs[3].)
 #define HEAD_DW_PIX 240
+#define HEAD_DW_NK 8
+#define HEAD_DW_LDS_FLOATS (15 * 1024)
 template <int DT>
 __global__ __launch_bounds__(512) void head_bwd_dw_tiled_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp,
                                                               int O, const float* __restrict__ dpred,
                                                               float* __restrict__ partial, int H, int W, int P, int Hh,
-                                                              int Wh) {
-  __shared__ float sd[HEAD_DW_PIX * 33];       // [pixel][o] (O <= 32), padded
-  __shared__ float sh[HEAD_DW_PIX * 33];       // [pixel][c] (Ch <= 32) + a constant 1 for the bias column
+                                                              int Wh, int stage) {
+  extern __shared__ __attribute__((aligned(16))) float smem_dw[];
+  const int SO = O | 1, SC = (Ch + 1) | 1;     // odd row strides: the staging writes walk pixels without bank conflicts
+  float* sd = smem_dw;                         // [pixel][o]
+  float* sh = smem_dw + stage * SO;            // [pixel][c] + a constant 1 for the bias column
   const int nout = O * (Ch + 1);
-  const int o = threadIdx.x / (Ch + 1), c = threadIdx.x % (Ch + 1);
+  int oo_[HEAD_DW_NK], cc_[HEAD_DW_NK];
+  float acc[HEAD_DW_NK];
+#pragma unroll
+  for (int k = 0; k < HEAD_DW_NK; ++k) {
+    const int i = min((int)threadIdx.x + 512 * k, nout - 1);
+    oo_[k] = i / (Ch + 1); cc_[k] = i % (Ch + 1); acc[k] = 0.f;
+  }
+  const int nk = (nout + 511) / 512;
   const size_t npix = (size_t)N * H * W;
   const size_t per = (npix + gridDim.x - 1) / gridDim.x;
   const size_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
   const int nq = (Ch + 3) / 4;                 // channel quads of a pixel (Chp is a multiple of 16: the vector load stays inside)
-  float acc = 0.f;
-  for (size_t base = p0; base < p1; base += HEAD_DW_PIX) {
-    const int cnt = (int)min((size_t)HEAD_DW_PIX, p1 - base);
+  for (size_t base = p0; base < p1; base += stage) {
+    const int cnt = (int)min((size_t)stage, p1 - base);
     __syncthreads();
     for (int i = threadIdx.x; i < cnt * O; i += 512) {        // dpred planes: consecutive threads walk consecutive pixels
       const int oo = i / cnt, pp = i - oo * cnt;
       const size_t pix = base + pp;
       const size_t yx = pix % ((size_t)H * W);
       const size_t n = pix / ((size_t)H * W);
-      sd[pp * 33 + oo] = dpred[(n * O + oo) * (size_t)H * W + yx];
+      sd[pp * SO + oo] = dpred[(n * O + oo) * (size_t)H * W + yx];
     }
     for (int i = threadIdx.x; i < cnt * nq; i += 512) {       // h: one 4-channel vector per thread
       const int pp = i / nq, q = i - pp * nq;
@@ -709,16 +721,26 @@ __global__ __launch_bounds__(512) void head_bwd_dw_tiled_kernel(const void* __re
       const f32x4_t v = load_vec4<DT>(h, ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp + 4 * q);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (4 * q + e < Ch) sh[pp * 33 + 4 * q + e] = v[e];
-      if (q == 0) sh[pp * 33 + Ch] = 1.f;
+        if (4 * q + e < Ch) sh[pp * SC + 4 * q + e] = v[e];
+      if (q == 0) sh[pp * SC + Ch] = 1.f;
     }
     __syncthreads();
-    if ((int)threadIdx.x < nout) {
+    if (nk == 1) {
+      if ((int)threadIdx.x < nout) {
 #pragma unroll 8
-      for (int pp = 0; pp < cnt; ++pp) acc += sd[pp * 33 + o] * sh[pp * 33 + c];
+        for (int pp = 0; pp < cnt; ++pp) acc[0] += sd[pp * SO + oo_[0]] * sh[pp * SC + cc_[0]];
+      }
+    } else {
+      for (int pp = 0; pp < cnt; ++pp) {
+#pragma unroll
+        for (int k = 0; k < HEAD_DW_NK; ++k)
+          if (k < nk) acc[k] += sd[pp * SO + oo_[k]] * sh[pp * SC + cc_[k]];
+      }
     }
   }
-  if ((int)threadIdx.x < nout) partial[(size_t)blockIdx.x * nout + threadIdx.x] = acc;
+#pragma unroll
+  for (int k = 0; k < HEAD_DW_NK; ++k)
+    if ((int)threadIdx.x + 512 * k < nout) partial[(size_t)blockIdx.x * nout + threadIdx.x + 512 * k] = acc[k];
 }
 
 // block = 64 outputs x blockDim/64 lanes over the per-workgroup partials; fixed order
@@ -748,11 +770,11 @@ extern "C" int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   const size_t total = (size_t)N * O * g->H * g->W, npix = (size_t)N * g->H * g->W;
   hipStream_t st = (hipStream_t)stream;
   const dim3 gp((unsigned)((npix + 255) / 256));
-  if (Chp <= 64 && Chp % 4 == 0) {
-    if (dtype == NINT_BF16 && Chp <= 32) hipLaunchKernelGGL((head_fwd_kernel<NINT_BF16, 32>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
-    else if (dtype == NINT_BF16) hipLaunchKernelGGL((head_fwd_kernel<NINT_BF16, 64>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
-    else if (Chp <= 32) hipLaunchKernelGGL((head_fwd_kernel<NINT_F32, 32>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
-    else hipLaunchKernelGGL((head_fwd_kernel<NINT_F32, 64>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
+  if (Chp <= 128 && Chp % 4 == 0) {
+#define NINT_HF(DT_, CHV_) hipLaunchKernelGGL((head_fwd_kernel<DT_, CHV_>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh)
+    if (dtype == NINT_BF16) { if (Chp <= 32) NINT_HF(NINT_BF16, 32); else if (Chp <= 64) NINT_HF(NINT_BF16, 64); else NINT_HF(NINT_BF16, 128); }
+    else { if (Chp <= 32) NINT_HF(NINT_F32, 32); else if (Chp <= 64) NINT_HF(NINT_F32, 64); else NINT_HF(NINT_F32, 128); }
+#undef NINT_HF
   } else if (dtype == NINT_BF16) {
     hipLaunchKernelGGL(head_fwd_wide_kernel<NINT_BF16>, grid1d(total), dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh);
   } else {
@@ -772,12 +794,14 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   if (dh) {
     const dim3 gp((unsigned)((npix + 255) / 256));
     const bool b16 = dtype == NINT_BF16;
+#define NINT_HD(DT_, CHV_) hipLaunchKernelGGL((head_bwd_dh_kernel<DT_, CHV_>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W)
     if (Chp <= 32 && Chp % 4 == 0) {
-      if (b16) hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_BF16, 32>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
-      else hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_F32, 32>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+      if (b16) NINT_HD(NINT_BF16, 32); else NINT_HD(NINT_F32, 32);
     } else if (Chp <= 64 && Chp % 4 == 0) {
-      if (b16) hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_BF16, 64>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
-      else hipLaunchKernelGGL((head_bwd_dh_kernel<NINT_F32, 64>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+      if (b16) NINT_HD(NINT_BF16, 64); else NINT_HD(NINT_F32, 64);
+    } else if (Chp <= 128 && Chp % 4 == 0) {
+      if (b16) NINT_HD(NINT_BF16, 128); else NINT_HD(NINT_F32, 128);
+#undef NINT_HD
     } else {
       if (b16) hipLaunchKernelGGL(head_bwd_dh_wide_kernel<NINT_BF16>, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
       else hipLaunchKernelGGL(head_bwd_dh_wide_kernel<NINT_F32>, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
@@ -785,14 +809,19 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
     NINT_LAUNCH_CHECK();
   }
   const int nout = O * (Ch + 1);
-  if (dw && db && scratch && nout <= 512 && O <= 32 && Ch <= 32 && scratch_bytes >= (size_t)256 * nout * sizeof(float)) {
+  const int row_floats = (O | 1) + ((Ch + 1) | 1);
+  if (dw && db && scratch && nout <= HEAD_DW_NK * 512 && 8 * row_floats <= HEAD_DW_LDS_FLOATS &&
+      scratch_bytes >= (size_t)256 * nout * sizeof(float)) {
+    int stage = HEAD_DW_LDS_FLOATS / row_floats;               // pixels staged at a time (60 KiB of LDS)
+    if (stage > HEAD_DW_PIX) stage = HEAD_DW_PIX;
+    const size_t lds = (size_t)stage * row_floats * sizeof(float);
     const size_t cap = scratch_bytes / ((size_t)nout * sizeof(float));
     const size_t want = (npix + HEAD_DW_PIX - 1) / HEAD_DW_PIX;
     const int nblk = (int)(want < cap ? want : cap);
     if (dtype == NINT_BF16)
-      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_BF16>, dim3(nblk), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
+      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_BF16>, dim3(nblk), dim3(512), lds, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh, stage);
     else
-      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_F32>, dim3(nblk), dim3(512), 0, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh);
+      hipLaunchKernelGGL(head_bwd_dw_tiled_kernel<NINT_F32>, dim3(nblk), dim3(512), lds, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh, stage);
     NINT_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(nint_cdiv(nout, 64)), dim3(1024), 0, st, scratch, nblk, Ch, O, dw, db);
     NINT_LAUNCH_CHECK();
@@ -906,37 +935,46 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
                                                               const float* __restrict__ y, float* __restrict__ dpred,
                                                               void* __restrict__ dh, double* __restrict__ partial, int H, int W,
                                                               int P, int Hh, int Wh, int oy, int ox, int Hc, int Wc) {
+  // A workgroup takes 64 pixels per pass (grid-stride).  Phase 1: wave q runs the outputs [q*OG, (q+1)*OG) of every pixel
+  // (lane = pixel): pred, loss terms, d loss / d pred -> dpred and, through LDS, to phase 2: wave q accumulates the
+  // channels [q*CHV/4, (q+1)*CHV/4) of dL/dh over ALL outputs in output order.  (One thread per pixel for all outputs --
+  // the first version -- is a chain of O dependent round trips on 1/4 of the threads: 50 us at B = 8, 44 us at B = 1.)
+  extern __shared__ __attribute__((aligned(16))) char smem_hl[];
+  float* gq_s = (float*)smem_hl;                 // [O][64]
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const size_t npix = (size_t)N * H * W;
   const double inv_n = 1.0 / ((double)N * O * Hc * Wc);
+  const int OG = (O + 3) / 4, ob = q * OG, oe = min(O, ob + OG);
+  constexpr int CQ = CHV / 4;                    // channels per wave in phase 2
   double s2 = 0, s1 = 0, sy = 0, syy = 0;
-  for (size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
-    const int x = pix % W;
-    size_t r = pix / W;
+  for (size_t p0 = (size_t)blockIdx.x * 64; p0 < npix; p0 += (size_t)gridDim.x * 64) {
+    const size_t pix = p0 + lane;
+    const bool live = pix < npix;
+    const size_t pc = live ? pix : npix - 1;
+    const int x = pc % W;
+    size_t r = pc / W;
     const int yy = r % H;
     const int n = r / H;
     const size_t hb = ((((size_t)(n0 + n)) * Hh + (yy + P)) * Wh + (x + P)) * Chp;
-    float hv[CHV], acc[CHV];
+    float hv[CHV];
 #pragma unroll
     for (int c = 0; c < CHV; c += 4) {
       const f32x4_t v = (c < Chp) ? load_vec4<DT>(h, hb + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
       hv[c] = v[0]; hv[c + 1] = v[1]; hv[c + 2] = v[2]; hv[c + 3] = v[3];
-      acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.f;
     }
     const int cy = yy - oy, cx = x - ox;
-    const bool in = cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+    const bool in = live && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
     float* dp = dpred + ((size_t)n * O * H + yy) * W + x;
     const float* yp = y + ((size_t)n * O * Hc + cy) * Wc + cx;
-    // the targets of OU outputs are fetched before they are used: one dependent HBM round trip per OU outputs instead
-    // of one per output (the sums below still run in output order).  (All 20 targets up front: 51 -> 62 us, measured.)
-    constexpr int OU = 4;
-    for (int o0 = 0; o0 < O; o0 += OU) {
+    constexpr int OU = 5;                        // targets fetched ahead of their use: one HBM round trip per OU outputs
+    for (int o0 = ob; o0 < oe; o0 += OU) {
       float tq[OU];
 #pragma unroll
-      for (int u = 0; u < OU; ++u) tq[u] = (in && o0 + u < O) ? yp[(size_t)(o0 + u) * Hc * Wc] : 0.f;
+      for (int u = 0; u < OU; ++u) tq[u] = (in && o0 + u < oe) ? yp[(size_t)(o0 + u) * Hc * Wc] : 0.f;
 #pragma unroll
       for (int u = 0; u < OU; ++u) {
         const int o = o0 + u;
-        if (o >= O) break;
+        if (o >= oe) break;
         float p = b ? b[o] : 0.f;
 #pragma unroll
         for (int c = 0; c < CHV; ++c)
@@ -951,22 +989,35 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
           syy += (double)t * t;
           gq = (float)((2.0 * d + (d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0))) * inv_n);
         }
-        dp[(size_t)o * H * W] = gq;
-#pragma unroll
-        for (int c = 0; c < CHV; ++c)
-          if (c < Ch) acc[c] += w[o * Ch + c] * gq;
+        if (live) dp[(size_t)o * H * W] = gq;
+        gq_s[o * 64 + lane] = gq;
       }
     }
+    __syncthreads();
+    // phase 2: dL/dh[c] = sum_o w[o][c] * gq[o], in output order (the order of head_bwd_dh_kernel)
+    float acc[CQ];
 #pragma unroll
-    for (int c = 0; c < CHV; c += 4)
-      if (c < Chp) store_vec4<DT>(dh, pix * Chp + c, (f32x4_t){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+    for (int c = 0; c < CQ; ++c) acc[c] = 0.f;
+    const int c0 = q * CQ;
+    for (int o = 0; o < O; ++o) {
+      const float gq = gq_s[o * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < CQ; ++c)
+        if (c0 + c < Ch) acc[c] += w[o * Ch + c0 + c] * gq;
+    }
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < CQ; c += 4)
+        if (c0 + c < Chp) store_vec4<DT>(dh, pix * Chp + c0 + c, (f32x4_t){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+    }
+    __syncthreads();                             // gq_s is rewritten by the next pass
   }
   __shared__ double red[4][256];
   red[0][threadIdx.x] = s2; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = sy; red[3][threadIdx.x] = syy;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s)
-      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+      for (int q2 = 0; q2 < 4; ++q2) red[q2][threadIdx.x] += red[q2][threadIdx.x + s];
     __syncthreads();
   }
   if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
@@ -978,18 +1029,19 @@ extern "C" int nint_head_loss_fused(const void* h_slab, int n0, int N, int Ch, i
   if (!h_slab || !w || !y || !dpred || !dh || !loss_out || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
   if (oy < 0 || ox < 0 || oy + Hc > g->H || ox + Wc > g->W) return NINT_E_ARG;
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
-  if (Chp > 64 || Chp % 4) return NINT_E_SHAPE;           // wider heads: nint_head_fwd + nint_loss_mse_l1_crop + nint_head_bwd
+  if (Chp > 128 || Chp % 4 || O > 256) return NINT_E_SHAPE;   // wider heads: nint_head_fwd + nint_loss_mse_l1_crop + nint_head_bwd
   if ((((uintptr_t)loss_out) & 7) != 0) return NINT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)(loss_out + 2);   // loss_out: [0]=loss, [1]=pad, [2..] = up to LOSS_BLOCKS_MAX*4 doubles
-  // one pixel per thread (the per-pixel loop over the outputs is long): up to LOSS_BLOCKS_MAX workgroups
+  // 64 pixels per workgroup and pass: up to LOSS_BLOCKS_MAX workgroups
   const size_t npix = (size_t)N * g->H * g->W;
-  const int nblk = (int)((npix + 255) / 256 < LOSS_BLOCKS_MAX ? (npix + 255) / 256 : LOSS_BLOCKS_MAX);
+  const int nblk = (int)((npix + 63) / 64 < LOSS_BLOCKS_MAX ? (npix + 63) / 64 : LOSS_BLOCKS_MAX);
   const dim3 grid(nblk);
-#define NINT_HL(DT_, CHV_) hipLaunchKernelGGL((head_loss_fused_kernel<DT_, CHV_>), grid, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, \
+  const size_t lds = (size_t)O * 64 * sizeof(float);      // (<= 64 KiB)
+#define NINT_HL(DT_, CHV_) hipLaunchKernelGGL((head_loss_fused_kernel<DT_, CHV_>), grid, dim3(256), lds, st, h_slab, n0, N, Ch, Chp, O, w, b, \
                                               y, dpred, dh, partial, g->H, g->W, g->P, g->Hh, g->Wh, oy, ox, Hc, Wc)
-  if (dtype == NINT_BF16) { if (Chp <= 32) NINT_HL(NINT_BF16, 32); else NINT_HL(NINT_BF16, 64); }
-  else { if (Chp <= 32) NINT_HL(NINT_F32, 32); else NINT_HL(NINT_F32, 64); }
+  if (dtype == NINT_BF16) { if (Chp <= 32) NINT_HL(NINT_BF16, 32); else if (Chp <= 64) NINT_HL(NINT_BF16, 64); else NINT_HL(NINT_BF16, 128); }
+  else { if (Chp <= 32) NINT_HL(NINT_F32, 32); else if (Chp <= 64) NINT_HL(NINT_F32, 64); else NINT_HL(NINT_F32, 128); }
 #undef NINT_HL
   NINT_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, nblk, loss_out, stats, (double)N * O * Hc * Wc);

@@ -90,9 +90,10 @@ extern "C" int nint_selftest(float* out, void* stream) {
 
 // ------------------------------------------------------------------------------ sequence drivers
 // Every launch of a pass is enqueued from C++ on the CALLER's stream, in dependency order.  The library owns no
-// streams, events or other state: measured on MI355X a (t, layer) wavefront on side streams and weight-gradient
+// streams, events or other state.  At the bench's batch size a (t, layer) wavefront on side streams and weight-gradient
 // reductions overlapped with the BPTT chain were both at or below this order (co-resident
-// MFMA-bound kernels evict each other's LDS / register budget), so they are not shipped.
+// MFMA-bound kernels evict each other's LDS / register budget); for small batches the caller can lend streams
+// and events for the forward wavefront (nint_seq.wave).
 static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
 
 __global__ void probe_stamp_kernel(unsigned long long* slot, unsigned long long tag) {
@@ -135,6 +136,25 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
   const int B = s->B, L = s->L;
   Probe probe = make_probe(s, false, stream);
+  // (t, layer) wavefront on the caller's side streams (nint_seq.wave): layer l runs on S[l]; gate(l, t) waits for the
+  // event recorded after gate(l-1, t); the in-order stream gives gate(l, t-1).  A later record of the same event does
+  // not disturb a wait that is already enqueued (the wait binds to the record that precedes it).
+  hipStream_t S[NINT_MAX_LAYERS];
+  hipEvent_t E[NINT_MAX_LAYERS + 1];
+  bool wave = s->wave != 0 && L > 1 && !probe.buf;
+  for (int l = 0; l < L; ++l) {
+    S[l] = (l > 0 && wave && s->wave_stream[l]) ? (hipStream_t)s->wave_stream[l] : (hipStream_t)stream;
+    E[l] = (hipEvent_t)s->wave_event[l];
+    if (!E[l]) wave = false;
+  }
+  E[L] = (hipEvent_t)s->wave_event[L];
+  if (!E[L]) wave = false;
+  if (!wave) for (int l = 0; l < L; ++l) S[l] = (hipStream_t)stream;
+  if (wave) {
+    NINT_CHECK_HIP(hipEventRecord(E[L], (hipStream_t)stream));           // fork: the side streams start behind the caller's work
+    for (int l = 1; l < L; ++l)
+      if (S[l] != (hipStream_t)stream) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], E[L], 0));
+  }
   for (int t = 0; t < s->T; ++t) {                               // model.py:265
     for (int l = 0; l < L; ++l) {                                // model.py:267
       const nint_layer* ly = &s->layer[l];
@@ -149,10 +169,19 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
       char* h_out = (char*)s->h[l] + (size_t)(t + 1) * hs;
       float* c_out = s->c[l] + (size_t)(t + 1) * cs;
       char* gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
+      if (wave && l > 0 && S[l] != S[l - 1]) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], E[l - 1], 0));
       probe.stamp(NINT_PROBE_GATE, l, t, 0);
-      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
+      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, S[l]);
       if (rc != NINT_OK) return rc;
       probe.stamp(NINT_PROBE_GATE, l, t, 1);
+      if (wave && (l + 1 < L ? S[l + 1] != S[l] : S[l] != (hipStream_t)stream)) NINT_CHECK_HIP(hipEventRecord(E[l], S[l]));
+    }
+  }
+  if (wave) {                                                    // join: the caller's stream continues behind every layer
+    for (int l = 1; l < L; ++l) {
+      if (S[l] == (hipStream_t)stream) continue;
+      if (l + 1 < L && S[l + 1] == S[l]) continue;               // (no record of its own: the next layer follows it on that stream)
+      NINT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, E[l], 0));
     }
   }
   return NINT_OK;

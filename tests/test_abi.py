@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in nint.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.nint_version() == _lib.NINT_VERSION == 107
+    assert lib.nint_version() == _lib.NINT_VERSION == 108
     assert lib.nint_kc(0) == 16 and lib.nint_kc(1) == 32
     assert lib.nint_error_string(-2).decode().startswith("nint:")
 
@@ -37,16 +37,16 @@ def test_struct_layout_matches_header(tmp_path):
     """Compile a tiny C program against nint.h and compare sizeof/offsetof with ctypes."""
     from nasa_niswan_amd import _lib
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nint.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nint.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(nint_geom),sizeof(nint_layer),sizeof(nint_seq),offsetof(nint_layer,Wf),offsetof(nint_seq,xs),'
                     'offsetof(nint_seq,dW),offsetof(nint_seq,wg_partial_bytes),offsetof(nint_layer,wide),'
-                    'offsetof(nint_seq,probe),offsetof(nint_seq,probe_slots));return 0;}\n')
+                    'offsetof(nint_seq,probe),offsetof(nint_seq,probe_slots),offsetof(nint_seq,wave),offsetof(nint_seq,wave_event));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.NintGeom), C.sizeof(_lib.NintLayer), C.sizeof(_lib.NintSeq), _lib.NintLayer.Wf.offset,
             _lib.NintSeq.xs.offset, _lib.NintSeq.dW.offset, _lib.NintSeq.wg_partial_bytes.offset, _lib.NintLayer.wide.offset,
-            _lib.NintSeq.probe.offset, _lib.NintSeq.probe_slots.offset]
+            _lib.NintSeq.probe.offset, _lib.NintSeq.probe_slots.offset, _lib.NintSeq.wave.offset, _lib.NintSeq.wave_event.offset]
     assert got == want
 
 

@@ -185,3 +185,42 @@ def test_k9_forward_works_and_training_is_refused_early(pkg):
     np.testing.assert_allclose(pred.numpy(), O.convlstm_forward(X, params).numpy(), rtol=1e-4, atol=1e-5)
     with pytest.raises(pkg.NintError, match="layer 0.*k=9"):
         net(X.cuda())
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+def test_forward_wavefront_on_side_streams_changes_no_bit(pkg, streams):
+    """nint_seq.wave (include/nint.h): the (t, layer) wavefront of the forward pass on streams and events the engine lends
+    -- the same launches in another enqueue order -- gives the serial order's prediction and gradients bit for bit, with
+    one side stream (layers 1.. share it) and with one per layer; the engine's own rule turns it on for B = 1 at the bench
+    grid and off for B = 8."""
+    from nasa_niswan_amd import engine
+    C, hidden, ks, out, B, T, H, W = 7, [24, 16, 8], [5, 3, 3], 2, 1, 5, 37, 50
+    torch.manual_seed(3)
+    X = torch.randn(B, T, C, H, W, device="cuda")
+    wgt = torch.randn(B, out, H, W, device="cuda")
+    res = {}
+    old = engine.FORCE_WAVE, engine.WAVE_STREAMS
+    try:
+        for wave in (0, 1):
+            engine.FORCE_WAVE, engine.WAVE_STREAMS = wave, streams
+            torch.manual_seed(4)
+            net = pkg.ConvLSTM(C, hidden, ks, 3, out_channels=out, compute_dtype="bf16").cuda()
+            for rep in range(2):                  # (the second pass reuses the workspace and the lent streams)
+                net.zero_grad()
+                pred = net(X)
+                (pred * wgt).sum().backward()
+            torch.cuda.synchronize()
+            res[wave] = [pred.detach().clone()] + [p.grad.clone() for p in net.parameters()]
+            assert {ws.seq.wave for pool in net._engine(X.device).pool.values() for ws in pool} == {wave}
+    finally:
+        engine.FORCE_WAVE, engine.WAVE_STREAMS = old
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    # the engine's rule (FORCE_WAVE None): B = 1 of the bench grid lends streams, B = 8 does not
+    assert engine.FORCE_WAVE is None
+    net = pkg.ConvLSTM(62, [64, 32, 16], [5, 3, 3], 3, out_channels=20, compute_dtype="bf16").cuda()
+    with torch.no_grad():
+        p1 = net(torch.randn(1, 2, 62, 100, 154, device="cuda"))
+        p8 = net(torch.randn(8, 2, 62, 100, 154, device="cuda"))
+    assert torch.isfinite(p1).all() and torch.isfinite(p8).all()
+    assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 1, 8: 0}

@@ -127,7 +127,7 @@ def test_loss_mse_l1_crop_matches_oracle(lib):
         assert abs(r2 - O.r2_score_np(y.numpy(), pc.numpy())) < 1e-7
 
 
-@pytest.mark.parametrize("dt,Ch,O", [(0, 16, 20), (1, 16, 20), (1, 8, 1), (0, 48, 3)])
+@pytest.mark.parametrize("dt,Ch,O", [(0, 16, 20), (1, 16, 20), (1, 8, 1), (0, 48, 3), (1, 128, 20), (0, 100, 3), (1, 16, 200)])
 def test_head_loss_fused_equals_the_three_separate_launches(lib, dt, Ch, O):
     """The training fast path nint_head_loss_fused (head forward + crop + MSE/L1 sums + dpred + dL/dh in one pass) must
     be bit-identical to nint_head_fwd -> nint_loss_mse_l1_crop -> nint_head_bwd, which the oracle tests pin; the
@@ -167,8 +167,21 @@ def test_head_loss_fused_equals_the_three_separate_launches(lib, dt, Ch, O):
     po = O_.crop_pred(O_.head_forward(hh, w.cpu().view(O, Ch, 1, 1), b.cpu()), halo, (Hc, Wc))
     lo = float(O_.loss_mse_l1(y.cpu(), po))
     assert abs(float(sc2[0]) - lo) <= 2e-6 * abs(lo)
-    assert lib.nint_head_loss_fused(P(hsl), n0, N, Ch, 96, O, P(w), P(b), P(y), P(dp2), P(dh2), P(sc2), P(st2), C.byref(g),
+    assert lib.nint_head_loss_fused(P(hsl), n0, N, Ch, 192, O, P(w), P(b), P(y), P(dp2), P(dh2), P(sc2), P(st2), C.byref(g),
                                     halo[0], halo[1], Hc, Wc, dt, None) == -2      # NINT_E_SHAPE: wider than the fused kernel holds
+    # the head's weight / bias gradient: the tiled two-stage path (scratch given) and the one-workgroup-per-output path
+    # against the plain contraction
+    hd = hsl[n0:n0 + N, Pd:Pd + H, Pd:Pd + W, :Ch].double()
+    dwr = torch.einsum("nohw,nhwc->oc", dp1.double(), hd)
+    dbr = dp1.double().sum(dim=(0, 2, 3))
+    for scratch_floats in (256 * O * (Ch + 1), 0):
+        dw, db = torch.zeros(O, Ch, device="cuda"), torch.zeros(O, device="cuda")
+        scr = torch.zeros(max(scratch_floats, 1), device="cuda")
+        assert lib.nint_head_bwd(P(hsl), n0, N, Ch, Chp, O, P(w), P(dp1), None, P(dw), P(db), C.byref(g), dt,
+                                 P(scr) if scratch_floats else None, scratch_floats * 4, None) == 0
+        torch.cuda.synchronize()
+        assert float((dw.double() - dwr).abs().max()) <= 1e-5 * float(dwr.abs().max()) + 1e-9
+        assert float((db.double() - dbr).abs().max()) <= 1e-5 * float(dbr.abs().max()) + 1e-9
 
 
 def test_adam_flat_matches_torch_golden(lib):
