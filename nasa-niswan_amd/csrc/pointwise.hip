@@ -545,10 +545,25 @@ extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g,
 // pred[n][o][y][x] = b[o] + sum_c w[o][c] * h[n][y][x][c]     (model.py:251,274)
 // One thread per pixel: the channel vector is read once (16-byte loads), the weights are wave-uniform
 // (scalar loads), and every output plane is written coalesced along x.  CHV = channels held in registers.
+// The weights are staged once per workgroup in LDS, zero-padded to [O][CHV]: the inner loop is then broadcast LDS reads and
+// FMAs with no bounds test (a predicate on the run-time channel count made every FMA a branch and a scalar load with its
+// own wait: 176 s_load_dword / 364 branches in the 32-channel instance).  The padding terms add +0.
+template <int CHV>
+__device__ __forceinline__ void head_stage_weights(float* w_s, const float* __restrict__ w, int O, int Ch) {
+  for (int i = threadIdx.x; i < O * CHV; i += blockDim.x) {
+    const int o = i / CHV, c = i - o * CHV;
+    w_s[i] = c < Ch ? w[o * Ch + c] : 0.f;
+  }
+  __syncthreads();
+}
+
 template <int DT, int CHV>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp, int O,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        float* __restrict__ pred, int H, int W, int P, int Hh, int Wh) {
+  extern __shared__ __attribute__((aligned(16))) char smem_hf[];
+  float* w_s = (float*)smem_hf;
+  head_stage_weights<CHV>(w_s, w, O, Ch);
   const size_t npix = (size_t)N * H * W;
   const size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (pix >= npix) return;
@@ -566,9 +581,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const void* __restrict__ 
   float* out = pred + ((size_t)n * O * H + y) * W + x;
   for (int o = 0; o < O; ++o) {
     float acc = b ? b[o] : 0.f;
+    const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV);
 #pragma unroll
-    for (int c = 0; c < CHV; ++c)
-      if (c < Ch) acc += w[o * Ch + c] * hv[c];
+    for (int c = 0; c < CHV; c += 4) {
+      const f32x4_t wv = wr[c / 4];
+      acc += wv[0] * hv[c]; acc += wv[1] * hv[c + 1]; acc += wv[2] * hv[c + 2]; acc += wv[3] * hv[c + 3];
+    }
     out[(size_t)o * H * W] = acc;
   }
 }
@@ -597,6 +615,9 @@ __global__ void head_fwd_wide_kernel(const void* __restrict__ h, int n0, int N, 
 template <int DT, int CHV>
 __global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restrict__ w, const float* __restrict__ dpred,
                                                           void* __restrict__ dh, int N, int Ch, int Chp, int O, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) char smem_hd[];
+  float* w_s = (float*)smem_hd;
+  head_stage_weights<CHV>(w_s, w, O, Ch);
   const size_t npix = (size_t)N * H * W;
   const size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (pix >= npix) return;
@@ -608,9 +629,12 @@ __global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restric
   const float* dp = dpred + n * O * (size_t)H * W + yx;
   for (int o = 0; o < O; ++o) {
     const float d = dp[(size_t)o * H * W];
+    const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV);
 #pragma unroll
-    for (int c = 0; c < CHV; ++c)
-      if (c < Ch) acc[c] += w[o * Ch + c] * d;
+    for (int c = 0; c < CHV; c += 4) {
+      const f32x4_t wv = wr[c / 4];
+      acc[c] += wv[0] * d; acc[c + 1] += wv[1] * d; acc[c + 2] += wv[2] * d; acc[c + 3] += wv[3] * d;
+    }
   }
 #pragma unroll
   for (int c = 0; c < CHV; c += 4)
@@ -770,8 +794,9 @@ extern "C" int nint_head_fwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   const size_t total = (size_t)N * O * g->H * g->W, npix = (size_t)N * g->H * g->W;
   hipStream_t st = (hipStream_t)stream;
   const dim3 gp((unsigned)((npix + 255) / 256));
-  if (Chp <= 128 && Chp % 4 == 0) {
-#define NINT_HF(DT_, CHV_) hipLaunchKernelGGL((head_fwd_kernel<DT_, CHV_>), gp, dim3(256), 0, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh)
+  const size_t w_lds = (size_t)O * (Chp <= 32 ? 32 : (Chp <= 64 ? 64 : 128)) * sizeof(float);      // staged weights [O][CHV]
+  if (Chp <= 128 && Chp % 4 == 0 && w_lds <= 64 * 1024) {
+#define NINT_HF(DT_, CHV_) hipLaunchKernelGGL((head_fwd_kernel<DT_, CHV_>), gp, dim3(256), w_lds, st, h_slab, n0, N, Ch, Chp, O, w, b, pred, g->H, g->W, g->P, g->Hh, g->Wh)
     if (dtype == NINT_BF16) { if (Chp <= 32) NINT_HF(NINT_BF16, 32); else if (Chp <= 64) NINT_HF(NINT_BF16, 64); else NINT_HF(NINT_BF16, 128); }
     else { if (Chp <= 32) NINT_HF(NINT_F32, 32); else if (Chp <= 64) NINT_HF(NINT_F32, 64); else NINT_HF(NINT_F32, 128); }
 #undef NINT_HF
@@ -794,8 +819,12 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   if (dh) {
     const dim3 gp((unsigned)((npix + 255) / 256));
     const bool b16 = dtype == NINT_BF16;
-#define NINT_HD(DT_, CHV_) hipLaunchKernelGGL((head_bwd_dh_kernel<DT_, CHV_>), gp, dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W)
-    if (Chp <= 32 && Chp % 4 == 0) {
+    const size_t w_lds = (size_t)O * (Chp <= 32 ? 32 : (Chp <= 64 ? 64 : 128)) * sizeof(float);    // staged weights [O][CHV]
+#define NINT_HD(DT_, CHV_) hipLaunchKernelGGL((head_bwd_dh_kernel<DT_, CHV_>), gp, dim3(256), w_lds, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W)
+    if (w_lds > 64 * 1024) {
+      if (b16) hipLaunchKernelGGL(head_bwd_dh_wide_kernel<NINT_BF16>, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+      else hipLaunchKernelGGL(head_bwd_dh_wide_kernel<NINT_F32>, grid1d(npix * Chp), dim3(256), 0, st, w, dpred, dh, N, Ch, Chp, O, g->H, g->W);
+    } else if (Chp <= 32 && Chp % 4 == 0) {
       if (b16) NINT_HD(NINT_BF16, 32); else NINT_HD(NINT_F32, 32);
     } else if (Chp <= 64 && Chp % 4 == 0) {
       if (b16) NINT_HD(NINT_BF16, 64); else NINT_HD(NINT_F32, 64);
@@ -940,8 +969,11 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
   // channels [q*CHV/4, (q+1)*CHV/4) of dL/dh over ALL outputs in output order.  (One thread per pixel for all outputs --
   // the first version -- is a chain of O dependent round trips on 1/4 of the threads: 50 us at B = 8, 44 us at B = 1.)
   extern __shared__ __attribute__((aligned(16))) char smem_hl[];
-  float* gq_s = (float*)smem_hl;                 // [O][64]
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  float* w_s = (float*)smem_hl;                  // [O][CHV], zero padded (head_stage_weights)
+  float* gq_s = w_s + O * CHV;                   // [O][64]
+  head_stage_weights<CHV>(w_s, w, O, Ch);
+  const int lane = threadIdx.x & 63;
+  const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the weight reads below stay scalar loads)
   const size_t npix = (size_t)N * H * W;
   const double inv_n = 1.0 / ((double)N * O * Hc * Wc);
   const int OG = (O + 3) / 4, ob = q * OG, oe = min(O, ob + OG);
@@ -976,9 +1008,12 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
         const int o = o0 + u;
         if (o >= oe) break;
         float p = b ? b[o] : 0.f;
+        const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV);
 #pragma unroll
-        for (int c = 0; c < CHV; ++c)
-          if (c < Ch) p += w[o * Ch + c] * hv[c];
+        for (int c = 0; c < CHV; c += 4) {
+          const f32x4_t wv = wr[c / 4];
+          p += wv[0] * hv[c]; p += wv[1] * hv[c + 1]; p += wv[2] * hv[c + 2]; p += wv[3] * hv[c + 3];
+        }
         float gq = 0.f;
         if (in) {
           const float t = tq[u];
@@ -1001,9 +1036,12 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
     const int c0 = q * CQ;
     for (int o = 0; o < O; ++o) {
       const float gq = gq_s[o * 64 + lane];
+      const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV + c0);
 #pragma unroll
-      for (int c = 0; c < CQ; ++c)
-        if (c0 + c < Ch) acc[c] += w[o * Ch + c0 + c] * gq;
+      for (int c = 0; c < CQ; c += 4) {
+        const f32x4_t wv = wr[c / 4];
+        acc[c] += wv[0] * gq; acc[c + 1] += wv[1] * gq; acc[c + 2] += wv[2] * gq; acc[c + 3] += wv[3] * gq;
+      }
     }
     if (live) {
 #pragma unroll
@@ -1029,7 +1067,7 @@ extern "C" int nint_head_loss_fused(const void* h_slab, int n0, int N, int Ch, i
   if (!h_slab || !w || !y || !dpred || !dh || !loss_out || !g || N <= 0 || O <= 0 || Ch <= 0) return NINT_E_ARG;
   if (oy < 0 || ox < 0 || oy + Hc > g->H || ox + Wc > g->W) return NINT_E_ARG;
   if (dtype != NINT_BF16 && dtype != NINT_F32) return NINT_E_ARG;
-  if (Chp > 128 || Chp % 4 || O > 256) return NINT_E_SHAPE;   // wider heads: nint_head_fwd + nint_loss_mse_l1_crop + nint_head_bwd
+  if (Chp > 128 || Chp % 4) return NINT_E_SHAPE;   // wider heads: nint_head_fwd + nint_loss_mse_l1_crop + nint_head_bwd
   if ((((uintptr_t)loss_out) & 7) != 0) return NINT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)(loss_out + 2);   // loss_out: [0]=loss, [1]=pad, [2..] = up to LOSS_BLOCKS_MAX*4 doubles
@@ -1037,11 +1075,15 @@ extern "C" int nint_head_loss_fused(const void* h_slab, int n0, int N, int Ch, i
   const size_t npix = (size_t)N * g->H * g->W;
   const int nblk = (int)((npix + 63) / 64 < LOSS_BLOCKS_MAX ? (npix + 63) / 64 : LOSS_BLOCKS_MAX);
   const dim3 grid(nblk);
-  const size_t lds = (size_t)O * 64 * sizeof(float);      // (<= 64 KiB)
-#define NINT_HL(DT_, CHV_) hipLaunchKernelGGL((head_loss_fused_kernel<DT_, CHV_>), grid, dim3(256), lds, st, h_slab, n0, N, Ch, Chp, O, w, b, \
-                                              y, dpred, dh, partial, g->H, g->W, g->P, g->Hh, g->Wh, oy, ox, Hc, Wc)
-  if (dtype == NINT_BF16) { if (Chp <= 32) NINT_HL(NINT_BF16, 32); else if (Chp <= 64) NINT_HL(NINT_BF16, 64); else NINT_HL(NINT_BF16, 128); }
-  else { if (Chp <= 32) NINT_HL(NINT_F32, 32); else if (Chp <= 64) NINT_HL(NINT_F32, 64); else NINT_HL(NINT_F32, 128); }
+  const int chv = Chp <= 32 ? 32 : (Chp <= 64 ? 64 : 128);
+  const size_t lds = (size_t)O * (chv + 64) * sizeof(float);      // weights [O][CHV] + d loss / d pred of 64 pixels [O][64]
+  if (lds + 8192 > 160 * 1024) return NINT_E_SHAPE;
+#define NINT_HL(DT_, CHV_) { auto kern = head_loss_fused_kernel<DT_, CHV_>;                                                                   \
+                             if (lds + 8192 > 64 * 1024) NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, h_slab, n0, N, Ch, Chp, O, w, b,                                \
+                                                y, dpred, dh, partial, g->H, g->W, g->P, g->Hh, g->Wh, oy, ox, Hc, Wc); }
+  if (dtype == NINT_BF16) { if (Chp <= 32) NINT_HL(NINT_BF16, 32) else if (Chp <= 64) NINT_HL(NINT_BF16, 64) else NINT_HL(NINT_BF16, 128) }
+  else { if (Chp <= 32) NINT_HL(NINT_F32, 32) else if (Chp <= 64) NINT_HL(NINT_F32, 64) else NINT_HL(NINT_F32, 128) }
 #undef NINT_HL
   NINT_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, nblk, loss_out, stats, (double)N * O * Hc * Wc);

@@ -326,12 +326,13 @@ class SeqEngine:
                         scratch: torch.Tensor, stats: torch.Tensor, halo, Hc: int, Wc: int) -> bool:
         """Training fast path (nint_head_loss_fused): head forward, crop, MSE+L1 sums, d loss / d pred and dL/dh_{T-1}
         (into ws.dh[-1]) in one pass; `scratch[0]` = loss, `stats` accumulated.  False when the head is wider than the
-        fused kernel holds (more than 128 padded channels or 256 outputs) (the caller then takes the three separate launches)."""
+        fused kernel holds (more than 128 padded channels, or weights + one pixel group's d loss / d pred beyond the LDS) (the caller then takes the three separate launches)."""
         l = len(self.cfgs) - 1
         cfg = self.cfgs[l]
         Chp = cfg.padded(self.kc)[2]
         O = w.shape[0]
-        if Chp > 128 or O > 256:
+        chv = 32 if Chp <= 32 else (64 if Chp <= 64 else 128)
+        if Chp > 128 or O * (chv + 64) * 4 + 8192 > 160 * 1024:
             return False
         w2 = w.detach().float().contiguous()
         b2 = None if b is None else b.detach().float().contiguous()

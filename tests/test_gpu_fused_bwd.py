@@ -77,9 +77,14 @@ def test_fused_step_equals_dgrad_then_pointwise(pkg, dtype, H, W, B):
         for name, (a, b) in pairs.items():
             a, b = a.double(), b.double()
             assert torch.isfinite(a).all(), (l, name)
-            if dtype == "f32" or name == "dx":
+            if dtype == "f32":
                 err, ref = float((a - b).abs().max()), float(b.abs().max())
                 assert err <= 1e-6 * ref + 1e-9, (l, name, err, ref)
+            elif name == "dx":
+                # the same f32 sums, rounded to bf16 once -- but small batches split the classic launch's columns over more
+                # workgroups (another K-slice order), so a sum may land on the other side of a bf16 rounding boundary
+                r = float((a - b).norm() / b.norm())
+                assert r <= 1e-3 and float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max()), (l, name, r)
             else:
                 r = float((a - b).norm() / b.norm())
                 assert r <= 1e-2, (l, name, r)
