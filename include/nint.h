@@ -114,16 +114,12 @@ typedef struct nint_seq {
                                         * fills slots from 0, nint_seq_bwd from probe_slots / 2; each starts with two back-to-back
                                         * calibration stamps (kind 0).  tag = kind | layer << 8 | t << 16 | end << 31 */
   int32_t probe_slots;
-  /* Optional (t, layer) wavefront of the FORWARD pass (model.py:265-271: gate(l, t) needs gate(l-1, t) and gate(l, t-1)
-   * only, so gate(0, t+1), gate(1, t), gate(2, t-1) are independent).  For the strong-scaling shape (B = 1-2 per GPU:
-   * one launch does not fill 256 CUs) the caller may lend streams and events: layer l >= 1 is then enqueued on
-   * wave_stream[l] (a NULL entry = the call's stream), ordered by wave_event[l] (recorded after every launch of layer
-   * l) and joined back into the call's stream before nint_seq_fwd returns; wave_event[L] forks.  All caller-owned
-   * hipStream_t / hipEvent_t handles (the library creates none); wave = 0 or any NULL event: plain order.
-   * Same launches, same results bit for bit. */
+  /* (t, layer) wavefront of the FORWARD pass (model.py:265-271: gate(l, t) needs gate(l-1, t) and gate(l, t-1) only, so
+   * gate(0, t+1), gate(1, t), gate(2, t-1) are independent).  wave != 0: each wavefront step is enqueued as ONE grid holding
+   * the workgroups of all its gate launches (T + L - 1 launches instead of T * L) -- for the strong-scaling shape (B = 1-2
+   * per GPU), where one layer's launch does not fill 256 CUs.  Same workgroups on the same data: bit-identical results.
+   * Falls back to one launch per (layer, step) for shapes the merged grid does not hold (8-row tiles, the 8-wave kernel). */
   int32_t wave;
-  void* wave_stream[NINT_MAX_LAYERS];
-  void* wave_event[NINT_MAX_LAYERS + 1];
 } nint_seq;
 
 /* launch kinds for nint_seq.probe_mask / the probe tags */

@@ -100,8 +100,10 @@ constexpr int xchg_rounds(int EPI, int WK, int NTW, int MT) {
   return (WK == 4 && MT == 4 && NTW % 2 == 0) ? 2 : ((WK == 4 && MT == 8 && NTW == 4) ? 4 : 1);
 }
 
+// The workgroup's work as a device function of (launch arguments, LDS base, workgroup coordinates): conv_igemm_kernel runs
+// it for blockIdx; conv_lstm_multi_kernel runs the gate launches of several layers (one wavefront step) in ONE grid.
 template <int DT, int EPI, int WN, int WK, int NTW, int MT>
-__global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) == 2 && DT == NINT_BF16 && EPI != EPI_DGRAD_PW ? 4 : 3)) void conv_igemm_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, const int bx_, const int by_, const int nbx_) {
   static_assert(WN * WK == 4, "four waves per workgroup");
   constexpr int BD = MT >= 8 ? BD_WIDE : BD_NARROW;
   static_assert(EPI != EPI_LSTM || NTW % 4 == 0, "LSTM epilogue needs the 4 gate tiles in one wave");
@@ -110,7 +112,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   constexpr int Q = MT / WK;       // rows whose epilogue this wave runs (K-slice waves split the rows)
   static_assert(MT % WK == 0, "K-slice waves split the tile rows evenly");
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   // pixels) and, at B = 8, whole images then stay inside one L2.  Any bijection is correct.
   int tile;
   {
-    const int nb = gridDim.x, b = blockIdx.x, q8 = nb / 8, r8 = nb % 8, x = b % 8, i = b / 8;
+    const int nb = nbx_, b = bx_, q8 = nb / 8, r8 = nb % 8, x = b % 8, i = b / 8;
     tile = x * q8 + (x < r8 ? x : r8) + i;     // ranges of q8 (+1 for the first r8 XCDs) tiles
   }
   // Two tile classes.  FULL tiles: MT rows x 16 pixels.  When the grid leaves 1..MT/2 rows over (100 = 12*8 + 4), the
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
     ty = a.tiles_full_y;
   }
   constexpr int RHM = MT >= 8 ? MT / 2 : MT;                   // rows of a merged tile
-  const int nt0 = a.nt_begin + blockIdx.y * NTWG + wn * NTW;   // first n-tile of this wave
+  const int nt0 = a.nt_begin + by_ * NTWG + wn * NTW;   // first n-tile of this wave
   const int y0 = ty * MT, x0 = mg ? tx * 32 : tx * 16;
   // row tile r of the workgroup sits at (y0 + rdy(r), x0 + rdx(r))
   auto rdy = [&](int r) __attribute__((always_inline)) { return mg ? r % RHM : r; };
@@ -666,9 +667,73 @@ __global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) =
   NINT_STAMP_AT(3)
 }
 
-// ------------------------------------------------------------------------------ host side
 template <int DT, int EPI, int WN, int WK, int NTW, int MT>
-static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
+__global__ __launch_bounds__(256, MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) == 2 && DT == NINT_BF16 && EPI != EPI_DGRAD_PW ? 4 : 3)) void conv_igemm_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_igemm_body<DT, EPI, WN, WK, NTW, MT>(a, smem, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// Independent launches in ONE grid.  Forward: one wavefront step -- gate(0, t+1), gate(1, t), gate(2, t-1), ... are
+// independent (model.py:265-271); backward: the bottom layer's dgrad of time u and the top layer's fused step of time u-1
+// (adjacent in the BPTT order, and they share no buffer in a stack of three or more layers).  At small batches (the
+// strong-scaling shape) none of these fills the chip -- run back to back each pays its own fill / epilogue latency on
+// half-empty CUs.  Workgroup ranges [begin[i], begin[i+1]) belong to problem i (each range starts at a multiple of 8, so a
+// problem's tile -> XCD mapping is the one of its own launch); every problem runs the body of the 4-row-tile shape its own
+// launch would have taken (ConvPlan::variant): same instructions on the same data, bit-identical results.  Registers / LDS
+// are those of the widest variant in the kernel.
+struct ConvMulti {
+  ConvArgs a[NINT_MULTI_MAX];
+  int n;
+  int begin[NINT_MULTI_MAX + 1];     // first workgroup of each problem (multiples of 8); begin[n] = grid size
+  int nbx[NINT_MULTI_MAX];           // pixel-tile workgroups of each problem (its launch's gridDim.x); column group = (b - begin) / nbx
+  int nwg[NINT_MULTI_MAX];           // nbx * column groups: workgroups past it are padding
+  int variant[NINT_MULTI_MAX];
+};
+constexpr int conv_variant(int EPI, int WN, int WK, int NTW, int MT) { return EPI * 10000 + WN * 1000 + WK * 100 + NTW * 10 + MT / 4; }
+#define NINT_MULTI_PROLOGUE                                                                                     \
+  extern __shared__ __attribute__((aligned(16))) char smem[];                                                   \
+  int i = 0;                                                                                                    \
+  _Pragma("unroll") for (int q = 1; q < NINT_MULTI_MAX; ++q) i += (q < m.n && (int)blockIdx.x >= m.begin[q]) ? 1 : 0; \
+  const int b = blockIdx.x - m.begin[i];                                                                        \
+  if (b >= m.nwg[i]) return;                   /* (padding up to the next multiple of 8) */                     \
+  const int nbx = m.nbx[i], by = b / nbx, bx = b - by * nbx;                                                    \
+  const ConvArgs& a = m.a[i];
+#define NINT_MULTI_CASE(EPI_, WN_, WK_, NTW_) \
+  case conv_variant(EPI_, WN_, WK_, NTW_, 4): conv_igemm_body<DT, EPI_, WN_, WK_, NTW_, 4>(a, smem, bx, by, nbx); break;
+template <int DT>
+__global__ __launch_bounds__(256, 3) void conv_lstm_multi_kernel(ConvMulti m) {
+  NINT_MULTI_PROLOGUE
+  switch (m.variant[i]) {
+    NINT_MULTI_CASE(EPI_LSTM, 4, 1, 4)
+    NINT_MULTI_CASE(EPI_LSTM, 2, 2, 4)
+    NINT_MULTI_CASE(EPI_LSTM, 1, 4, 4)
+    default: break;
+  }
+}
+template <int DT>
+__global__ __launch_bounds__(256, 3) void conv_bwd_multi_kernel(ConvMulti m) {
+  NINT_MULTI_PROLOGUE
+  switch (m.variant[i]) {
+    NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 4)
+    NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 2)
+    NINT_MULTI_CASE(EPI_DGRAD_PW, 1, 4, 3)
+    default: break;                            // (the register-heavy fused shapes -- 4 column tiles per wave -- would spill at 168 VGPRs)
+  }
+}
+static bool multi_holds(int variant) {
+  switch (variant) {
+    case conv_variant(EPI_LSTM, 4, 1, 4, 4): case conv_variant(EPI_LSTM, 2, 2, 4, 4): case conv_variant(EPI_LSTM, 1, 4, 4, 4):
+    case conv_variant(EPI_DGRAD, 1, 4, 4, 4): case conv_variant(EPI_DGRAD, 1, 4, 2, 4): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 4):
+      return true;
+    default: return false;
+  }
+}
+
+// ------------------------------------------------------------------------------ host side
+// (ConvPlan, nint_common.h: a launch that is planned but not enqueued; the sequence drivers collect independent ones and
+// enqueue them as one grid)
+template <int DT, int EPI, int WN, int WK, int NTW, int MT>
+static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st, ConvPlan* plan = nullptr) {
   const int NHP = (MT + 2 * a.p) * (16 + 2 * a.p);
   a.nhp_pad = nint_round_up(NHP, 16);
   a.magic_nhpp = (unsigned)(((1ull << 32) + a.nhp_pad - 1) / a.nhp_pad);
@@ -704,6 +769,11 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
   size_t lds = (size_t)a.a_bytes;
   if ((size_t)red_bytes > lds) lds = red_bytes;
   if (lds > 160 * 1024) return NINT_E_LDS;
+  if (plan) {
+    plan->a = a; plan->gx = a.n_full + N * a.tiles_x2; plan->gy = ngroups_y; plan->lds = lds;
+    plan->variant = conv_variant(EPI, WN, WK, NTW, MT);
+    return NINT_OK;
+  }
   auto kern = conv_igemm_kernel<DT, EPI, WN, WK, NTW, MT>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -717,8 +787,8 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st) {
 #define NINT_SPLIT_NUM 3        // small batches: split the columns while workgroups < NINT_SPLIT_NUM / 2 per CU
 #endif
 template <int DT, int EPI>
-static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
-  if (ntiles <= 0) return NINT_OK;
+static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st, ConvPlan* plan = nullptr) {
+  if (ntiles <= 0) return NINT_OK;             // (a plan keeps gx == 0)
   // short-K launches (narrow layers) take 4-row tiles; nint_layer.tile_rows = 4 | 8 overrides (tests run both
   // heights on every shape)
   const int ksteps = a.nchunk0 * a.k * a.kx0 + a.nchunk1 * a.taps;
@@ -740,31 +810,31 @@ static int launch_conv(ConvArgs& a, int N, int ntiles, hipStream_t st) {
     // (an explicit nint_layer.tile_rows pins the launch shape: no split)
     const bool few4 = !a.tile_rows && 2 * ptiles * (cbs / 4 > 0 ? cbs / 4 : 1) < NINT_SPLIT_NUM * n_cu;       // with 4 column blocks per workgroup
     const bool few2 = !a.tile_rows && 2 * ptiles * (cbs / 2 > 0 ? cbs / 2 : 1) < NINT_SPLIT_NUM * n_cu;       // with 2
-    if (cbs % 4 == 0 && !few4) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, cbs / 4, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, cbs / 4, st);
-    if (cbs % 2 == 0 && !few2) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st);
-    return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st);
+    if (cbs % 4 == 0 && !few4) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, cbs / 4, st, plan) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, cbs / 4, st, plan);
+    if (cbs % 2 == 0 && !few2) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, cbs / 2, st, plan) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, cbs / 2, st, plan);
+    return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, cbs, st, plan) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, cbs, st, plan);
   } else {
     // (WN, NTW) with WN*NTW dividing the tile count, widest first; leftover waves split K.  Small batches: a shape whose
     // launch would leave CUs without a workgroup is passed over for the next narrower one (more column groups on
     // blockIdx.y; the same rule as the gate launches above)
     const int ptiles = N * nint_cdiv(a.W, 16) * nint_cdiv(a.H, mt4 ? 4 : 8);
     auto few = [&](int cols) { return !a.tile_rows && EPI == EPI_DGRAD && 2 * ptiles * (ntiles / cols) < NINT_SPLIT_NUM * n_cu; };
-    if (ntiles % 16 == 0 && !few(16)) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, ntiles / 16, st) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, ntiles / 16, st);
-    if (ntiles % 12 == 0 && !few(12)) return mt4 ? launch_cfg<DT, EPI, 4, 1, 3, 4>(a, N, ntiles / 12, st) : launch_cfg<DT, EPI, 4, 1, 3, 8>(a, N, ntiles / 12, st);
-    if (ntiles % 8 == 0 && !few(8)) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, ntiles / 8, st) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, ntiles / 8, st);
-    if (ntiles % 6 == 0 && !few(6)) return mt4 ? launch_cfg<DT, EPI, 2, 2, 3, 4>(a, N, ntiles / 6, st) : launch_cfg<DT, EPI, 2, 2, 3, 8>(a, N, ntiles / 6, st);
-    if (ntiles % 4 == 0 && !few(4)) return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, ntiles / 4, st) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, ntiles / 4, st);
-    if (ntiles % 3 == 0 && !few(3)) return mt4 ? launch_cfg<DT, EPI, 1, 4, 3, 4>(a, N, ntiles / 3, st) : launch_cfg<DT, EPI, 1, 4, 3, 8>(a, N, ntiles / 3, st);
-    if (ntiles % 2 == 0 && !few(2)) return mt4 ? launch_cfg<DT, EPI, 1, 4, 2, 4>(a, N, ntiles / 2, st) : launch_cfg<DT, EPI, 1, 4, 2, 8>(a, N, ntiles / 2, st);
-    return mt4 ? launch_cfg<DT, EPI, 1, 4, 1, 4>(a, N, ntiles, st) : launch_cfg<DT, EPI, 1, 4, 1, 8>(a, N, ntiles, st);
+    if (ntiles % 16 == 0 && !few(16)) return mt4 ? launch_cfg<DT, EPI, 4, 1, 4, 4>(a, N, ntiles / 16, st, plan) : launch_cfg<DT, EPI, 4, 1, 4, 8>(a, N, ntiles / 16, st, plan);
+    if (ntiles % 12 == 0 && !few(12)) return mt4 ? launch_cfg<DT, EPI, 4, 1, 3, 4>(a, N, ntiles / 12, st, plan) : launch_cfg<DT, EPI, 4, 1, 3, 8>(a, N, ntiles / 12, st, plan);
+    if (ntiles % 8 == 0 && !few(8)) return mt4 ? launch_cfg<DT, EPI, 2, 2, 4, 4>(a, N, ntiles / 8, st, plan) : launch_cfg<DT, EPI, 2, 2, 4, 8>(a, N, ntiles / 8, st, plan);
+    if (ntiles % 6 == 0 && !few(6)) return mt4 ? launch_cfg<DT, EPI, 2, 2, 3, 4>(a, N, ntiles / 6, st, plan) : launch_cfg<DT, EPI, 2, 2, 3, 8>(a, N, ntiles / 6, st, plan);
+    if (ntiles % 4 == 0 && !few(4)) return mt4 ? launch_cfg<DT, EPI, 1, 4, 4, 4>(a, N, ntiles / 4, st, plan) : launch_cfg<DT, EPI, 1, 4, 4, 8>(a, N, ntiles / 4, st, plan);
+    if (ntiles % 3 == 0 && !few(3)) return mt4 ? launch_cfg<DT, EPI, 1, 4, 3, 4>(a, N, ntiles / 3, st, plan) : launch_cfg<DT, EPI, 1, 4, 3, 8>(a, N, ntiles / 3, st, plan);
+    if (ntiles % 2 == 0 && !few(2)) return mt4 ? launch_cfg<DT, EPI, 1, 4, 2, 4>(a, N, ntiles / 2, st, plan) : launch_cfg<DT, EPI, 1, 4, 2, 8>(a, N, ntiles / 2, st, plan);
+    return mt4 ? launch_cfg<DT, EPI, 1, 4, 1, 4>(a, N, ntiles, st, plan) : launch_cfg<DT, EPI, 1, 4, 1, 8>(a, N, ntiles, st, plan);
   }
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
-                             const void* x_slab, const void* h_prev, const float* c_prev,
-                             void* h_out, float* c_out, void* gates_out, void* stream) {
+static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
+                    const void* x_slab, const void* h_prev, const float* c_prev,
+                    void* h_out, float* c_out, void* gates_out, void* stream, ConvPlan* plan) {
   if (!ly || !g || !x_slab || !h_out || !c_out || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!(ly->k & 1) || ly->k / 2 > g->P) return NINT_E_ARG;
@@ -794,12 +864,54 @@ extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype
   a.tile_rows = ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
   if (ly->wide < 0 || ly->wide > 12 || (ly->wide & 7) > 4) return NINT_E_ARG;
-  if (dtype == NINT_BF16 && (ly->wide & 7) != 1) {     // wide layers with enough tiles: the 8-wave LDS-weight kernel (conv_wide.hip)
+  if (plan && (ly->wide & 7) > 1) return NINT_E_SHAPE;  // (the 8-wave kernel is a launch of its own)
+  if (!plan && dtype == NINT_BF16 && (ly->wide & 7) != 1) {     // wide layers with enough tiles: the 8-wave LDS-weight kernel (conv_wide.hip)
     const int rc = nint_internal_conv_wide_lstm(a, N, ly->wide, stream);
     if (rc != NINT_E_SHAPE) return rc;
   }
-  return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st)
-                            : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st);
+  return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st, plan)
+                            : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st, plan);
+}
+
+extern "C" int nint_cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
+                             const void* x_slab, const void* h_prev, const float* c_prev,
+                             void* h_out, float* c_out, void* gates_out, void* stream) {
+  return cell_fwd(ly, g, dtype, N, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream, nullptr);
+}
+
+int nint_internal_cell_fwd_plan(const CellFwdJob* j, const nint_geom* g, int dtype, int N, ConvPlan* plan) {
+  return cell_fwd(j->ly, g, dtype, N, j->x_slab, j->h_prev, j->c_prev, j->h_out, j->c_out, j->gates_out, nullptr, plan);
+}
+
+// Up to NINT_MULTI_MAX planned launches that do not depend on each other, as ONE grid.  NINT_E_SHAPE (nothing enqueued): one
+// of them has a shape the merged kernels do not hold, or they are of both kinds -- the caller then enqueues them one by one.
+int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream) {
+  if (!plans || n < 1 || n > NINT_MULTI_MAX) return NINT_E_SHAPE;
+  ConvMulti m = {};
+  size_t lds = 0;
+  int b = 0, nfwd = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvPlan& pl = plans[i];
+    if (!multi_holds(pl.variant)) return NINT_E_SHAPE;
+    nfwd += pl.variant / 10000 == EPI_LSTM ? 1 : 0;
+    m.a[i] = pl.a; m.variant[i] = pl.variant; m.nbx[i] = pl.gx; m.nwg[i] = pl.gx * pl.gy;
+    m.begin[i] = b;
+    b += nint_round_up(pl.gx * pl.gy, 8);
+    if (pl.lds > lds) lds = pl.lds;
+  }
+  if (nfwd != 0 && nfwd != n) return NINT_E_SHAPE;
+  m.n = n;
+  for (int i = n; i <= NINT_MULTI_MAX; ++i) m.begin[i] = b;
+  hipStream_t st = (hipStream_t)stream;
+#define NINT_MULTI_LAUNCH(KERN_)                                                                                                      \
+  { auto kern = KERN_;                                                                                                                \
+    if (lds > 64 * 1024) NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(256), lds, st, m); }
+  if (nfwd) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_F32>) }
+  else { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_bwd_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_bwd_multi_kernel<NINT_F32>) }
+#undef NINT_MULTI_LAUNCH
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
 }
 
 extern "C" int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N,
@@ -807,8 +919,10 @@ extern "C" int nint_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dty
   return nint_internal_conv_dgrad(ly, g, dtype, N, dG, dx_accum, dh_prev, false, nullptr, stream);
 }
 
+// plan != nullptr: nothing is enqueued, *plan describes the launch (plan->gx == 0: there is nothing to launch)
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
-                             void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream) {
+                             void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream, ConvPlan* plan) {
+  if (plan) plan->gx = 0;
   if (!ly || !g || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   // fused forms: pw->gates set = this layer's pointwise backward on the h columns (dh_prev is then not stored);
@@ -851,11 +965,11 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
       a.lo_dG = (char*)pw->lo_dG_out; a.lo_Ch16 = pw->lo_Ch16; a.lo_dc_zero = pw->lo_dc_zero ? 1 : 0;
     }
     if (pw->tile_rows) a.tile_rows = pw->tile_rows;
-    return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD_PW>(a, N, ntiles, st)
-                              : launch_conv<NINT_F32, EPI_DGRAD_PW>(a, N, ntiles, st);
+    return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD_PW>(a, N, ntiles, st, plan)
+                              : launch_conv<NINT_F32, EPI_DGRAD_PW>(a, N, ntiles, st, plan);
   }
-  return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD>(a, N, ntiles, st)
-                            : launch_conv<NINT_F32, EPI_DGRAD>(a, N, ntiles, st);
+  return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_DGRAD>(a, N, ntiles, st, plan)
+                            : launch_conv<NINT_F32, EPI_DGRAD>(a, N, ntiles, st, plan);
 }
 
 extern "C" int nint_cell_bwd_fused(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG_next, void* dx,

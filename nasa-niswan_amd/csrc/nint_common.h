@@ -178,6 +178,17 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
 // conv_wide.hip: the persistent 8-wave gate kernel with the weight tiles staged once per workgroup in LDS (bf16, wide layers).
 // force = nint_layer.wide == 2.  NINT_E_SHAPE = not served: the caller takes conv_igemm.hip's 4-wave kernel.
 int nint_internal_conv_wide_lstm(const ConvArgs& a, int N, int force, void* stream);
+#define NINT_MULTI_MAX 4  // problems per merged grid (conv_lstm_multi_kernel / conv_bwd_multi_kernel)
+struct CellFwdJob {      // one gate launch (nint_cell_fwd's arguments)
+  const nint_layer* ly; const void* x_slab; const void* h_prev; const float* c_prev; void* h_out; float* c_out; void* gates_out;
+};
+// A conv_igemm launch that is planned but not enqueued: the sequence drivers collect independent ones and enqueue them as ONE
+// grid (nint_internal_conv_multi; NINT_E_SHAPE = not possible for these shapes, nothing enqueued).
+struct ConvPlan {
+  ConvArgs a; int gx, gy; size_t lds; int variant;   // grid, dynamic LDS, kernel shape (EPI, WN, WK, NTW, MT)
+};
+int nint_internal_cell_fwd_plan(const CellFwdJob* j, const nint_geom* g, int dtype, int N, ConvPlan* plan);
+int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream);
 struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
   // optional: the layer below's pointwise backward of THIS time step, run on the x columns (the layer's dh buffer is only read)
@@ -185,4 +196,4 @@ struct DgradPw {         // fused pointwise backward of the previous time step (
   int tile_rows;          // 0 = the layer's choice, 4 / 8 = this launch's tile height
 };
 int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* dG, void* dx_accum,
-                             void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream);
+                             void* dh_prev, bool overwrite_dx, const DgradPw* pw, void* stream, ConvPlan* plan = nullptr);

@@ -92,8 +92,8 @@ extern "C" int nint_selftest(float* out, void* stream) {
 // Every launch of a pass is enqueued from C++ on the CALLER's stream, in dependency order.  The library owns no
 // streams, events or other state.  At the bench's batch size a (t, layer) wavefront on side streams and weight-gradient
 // reductions overlapped with the BPTT chain were both at or below this order (co-resident
-// MFMA-bound kernels evict each other's LDS / register budget); for small batches the caller can lend streams
-// and events for the forward wavefront (nint_seq.wave).
+// MFMA-bound kernels evict each other's LDS / register budget; every cross-stream edge is a marker on the first layer's
+// chain).  For small batches the forward wavefront runs as ONE grid per step instead (nint_seq.wave, conv_lstm_multi_kernel).
 static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
 
 __global__ void probe_stamp_kernel(unsigned long long* slot, unsigned long long tag) {
@@ -136,52 +136,61 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   const size_t halo_px = (size_t)g->Hh * g->Wh, comp_px = (size_t)g->H * g->W;
   const int B = s->B, L = s->L;
   Probe probe = make_probe(s, false, stream);
-  // (t, layer) wavefront on the caller's side streams (nint_seq.wave): layer l runs on S[l]; gate(l, t) waits for the
-  // event recorded after gate(l-1, t); the in-order stream gives gate(l, t-1).  A later record of the same event does
-  // not disturb a wait that is already enqueued (the wait binds to the record that precedes it).
-  hipStream_t S[NINT_MAX_LAYERS];
-  hipEvent_t E[NINT_MAX_LAYERS + 1];
-  bool wave = s->wave != 0 && L > 1 && !probe.buf;
-  for (int l = 0; l < L; ++l) {
-    S[l] = (l > 0 && wave && s->wave_stream[l]) ? (hipStream_t)s->wave_stream[l] : (hipStream_t)stream;
-    E[l] = (hipEvent_t)s->wave_event[l];
-    if (!E[l]) wave = false;
-  }
-  E[L] = (hipEvent_t)s->wave_event[L];
-  if (!E[L]) wave = false;
-  if (!wave) for (int l = 0; l < L; ++l) S[l] = (hipStream_t)stream;
-  if (wave) {
-    NINT_CHECK_HIP(hipEventRecord(E[L], (hipStream_t)stream));           // fork: the side streams start behind the caller's work
-    for (int l = 1; l < L; ++l)
-      if (S[l] != (hipStream_t)stream) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], E[L], 0));
+  auto job = [&](int l, int t) {
+    const nint_layer* ly = &s->layer[l];
+    const char* x_slab = (l == 0)
+        ? (const char*)s->xs + (size_t)t * B * halo_px * ly->Cxp * es            // x[:, t]  (model.py:266)
+        : (const char*)s->h[l - 1] + (size_t)(t + 1) * B * halo_px * ly->Cxp * es;  // h of the layer below (model.py:271)
+    const size_t hs = (size_t)B * halo_px * ly->Chp * es;
+    const size_t cs = (size_t)B * comp_px * ly->Chp;
+    const bool zero_state = (t == 0 && !s->has_init_state);     // model.py:259-262: zeros -> skip the h half of K
+    CellFwdJob j;
+    j.ly = ly; j.x_slab = x_slab;
+    j.h_prev = zero_state ? nullptr : (const char*)s->h[l] + (size_t)t * hs;
+    j.c_prev = zero_state ? nullptr : s->c[l] + (size_t)t * cs;
+    j.h_out = (char*)s->h[l] + (size_t)(t + 1) * hs;
+    j.c_out = s->c[l] + (size_t)(t + 1) * cs;
+    j.gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
+    return j;
+  };
+  auto launch = [&](int l, int t) {
+    const CellFwdJob j = job(l, t);
+    probe.stamp(NINT_PROBE_GATE, l, t, 0);
+    const int r = nint_cell_fwd(j.ly, g, s->dtype, B, j.x_slab, j.h_prev, j.c_prev, j.h_out, j.c_out, j.gates_out, stream);
+    probe.stamp(NINT_PROBE_GATE, l, t, 1);
+    return r;
+  };
+  if (s->wave && L > 1 && L <= NINT_MULTI_MAX && !probe.buf) {
+    // (t, layer) WAVEFRONT: step w runs gate(l, w - l) of every layer -- each needs gate(l-1, w-l) and gate(l, w-l-1), both
+    // of step w-1 -- as ONE grid (conv_lstm_multi_kernel).  T + L - 1 launches instead of T * L; the same workgroups
+    // on the same data, so the results are those of the time-major order bit for bit.
+    for (int w = 0; w < s->T + L - 1; ++w) {
+      ConvPlan plans[NINT_MULTI_MAX];
+      int lt[NINT_MULTI_MAX][2], n = 0;
+      rc = NINT_OK;
+      for (int l = 0; l < L && rc == NINT_OK; ++l) {
+        const int t = w - l;
+        if (t < 0 || t >= s->T) continue;
+        const CellFwdJob j = job(l, t);
+        rc = nint_internal_cell_fwd_plan(&j, g, s->dtype, B, &plans[n]);
+        lt[n][0] = l; lt[n][1] = t; ++n;
+      }
+      if (rc == NINT_OK) rc = n > 1 ? nint_internal_conv_multi(plans, n, s->dtype, stream) : NINT_E_SHAPE;
+      if (rc == NINT_E_SHAPE) {                // a shape the merged grid does not hold (or a single launch): one by one
+        for (int q = 0; q < n; ++q) {
+          rc = launch(lt[q][0], lt[q][1]);
+          if (rc != NINT_OK) return rc;
+        }
+      } else if (rc != NINT_OK) {
+        return rc;
+      }
+    }
+    return NINT_OK;
   }
   for (int t = 0; t < s->T; ++t) {                               // model.py:265
     for (int l = 0; l < L; ++l) {                                // model.py:267
-      const nint_layer* ly = &s->layer[l];
-      const char* x_slab = (l == 0)
-          ? (const char*)s->xs + (size_t)t * B * halo_px * ly->Cxp * es            // x[:, t]  (model.py:266)
-          : (const char*)s->h[l - 1] + (size_t)(t + 1) * B * halo_px * ly->Cxp * es;  // h of the layer below (model.py:271)
-      const size_t hs = (size_t)B * halo_px * ly->Chp * es;
-      const size_t cs = (size_t)B * comp_px * ly->Chp;
-      const bool zero_state = (t == 0 && !s->has_init_state);     // model.py:259-262: zeros -> skip the h half of K
-      const char* h_prev = zero_state ? nullptr : (const char*)s->h[l] + (size_t)t * hs;
-      const float* c_prev = zero_state ? nullptr : s->c[l] + (size_t)t * cs;
-      char* h_out = (char*)s->h[l] + (size_t)(t + 1) * hs;
-      float* c_out = s->c[l] + (size_t)(t + 1) * cs;
-      char* gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
-      if (wave && l > 0 && S[l] != S[l - 1]) NINT_CHECK_HIP(hipStreamWaitEvent(S[l], E[l - 1], 0));
-      probe.stamp(NINT_PROBE_GATE, l, t, 0);
-      rc = nint_cell_fwd(ly, g, s->dtype, B, x_slab, h_prev, c_prev, h_out, c_out, gates_out, S[l]);
+      rc = launch(l, t);
       if (rc != NINT_OK) return rc;
-      probe.stamp(NINT_PROBE_GATE, l, t, 1);
-      if (wave && (l + 1 < L ? S[l + 1] != S[l] : S[l] != (hipStream_t)stream)) NINT_CHECK_HIP(hipEventRecord(E[l], S[l]));
-    }
-  }
-  if (wave) {                                                    // join: the caller's stream continues behind every layer
-    for (int l = 1; l < L; ++l) {
-      if (S[l] == (hipStream_t)stream) continue;
-      if (l + 1 < L && S[l + 1] == S[l]) continue;               // (no record of its own: the next layer follows it on that stream)
-      NINT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, E[l], 0));
     }
   }
   return NINT_OK;
@@ -236,6 +245,17 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   }
   const int T = s->T;
   Probe probe = make_probe(s, true, stream);
+  // Small batches (nint_seq.wave): the bottom layer's dgrad of one outer step and the top layer's fused step of the next are
+  // ADJACENT launches that share no buffer when the stack has three or more layers (the top layer's step touches its own
+  // state and layer L-2's; the bottom dgrad reads dG[0] and writes dh[0] / dx): they go out as ONE grid
+  // (nint_internal_conv_multi).  The bottom dgrad is held back (`pend`) until the next launch is known.
+  const bool merge = s->wave && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];
+  struct { bool on; ConvPlan plan; const void* dG; void* dx; void* dh_prev; bool ow; } pend = {};
+  auto flush = [&]() {                           // the held-back dgrad as a launch of its own
+    if (!pend.on) return (int)NINT_OK;
+    pend.on = false;
+    return nint_internal_conv_dgrad(&s->layer[0], g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream);
+  };
   for (int so = T - 1; so >= -off[0]; --so) {
     for (int l = L - 1; l >= 0; --l) {
       const int u = so + off[l];
@@ -247,6 +267,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       auto pointwise = [&](int t) {      // consumes dh[l] / dc[l] of time t, writes dG of time t
         // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
+        { const int rf = flush(); if (rf != NINT_OK) return rf; }
         probe.stamp(NINT_PROBE_POINTWISE, l, t, 0);
         const int r = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, (const char*)s->gates[l] + (size_t)t * gs, s->c[l] + (size_t)t * cs,
                                                        s->c[l] + (size_t)(t + 1) * cs, s->dh[l], s->dc[l], (char*)s->dG[l] + (size_t)t * dgs,
@@ -279,6 +300,15 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           pw.tile_rows = 4;
           pw_done[l - 1] = u;
         }
+        rc = flush();
+        if (rc != NINT_OK) return rc;
+        if (merge && l == 0 && so > -off[0]) {  // (not the very last launch: there is a top-layer step to pair it with)
+          pend.dG = (const char*)s->dG[l] + (size_t)u * dgs; pend.dx = dx_dst; pend.dh_prev = dh_prev; pend.ow = ow;
+          rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream, &pend.plan);
+          if (rc != NINT_OK) return rc;
+          pend.on = pend.plan.gx > 0;
+          continue;
+        }
         probe.stamp(NINT_PROBE_DGRAD, l, u, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, loc[l] ? &pw : nullptr, stream);
         probe.stamp(NINT_PROBE_DGRAD, l, u, 1);
@@ -299,10 +329,23 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           pw.lo_dc_zero = u == T - 1 && ((s->zero_dstate >> (2 * (l - 1))) & 1);
           pw_done[l - 1] = u;
         }
+        if (pend.on && l == L - 1) {             // the top layer's step right behind the held-back bottom dgrad: one grid
+          ConvPlan pl[2];
+          pl[0] = pend.plan;
+          rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream, &pl[1]);
+          if (rc != NINT_OK) return rc;
+          rc = pl[1].gx > 0 ? nint_internal_conv_multi(pl, 2, s->dtype, stream) : NINT_E_SHAPE;
+          if (rc == NINT_OK) { pend.on = false; continue; }
+          if (rc != NINT_E_SHAPE) return rc;
+        }
+        rc = flush();
+        if (rc != NINT_OK) return rc;
         probe.stamp(NINT_PROBE_FUSED, l, u, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream);
         probe.stamp(NINT_PROBE_FUSED, l, u, 1);
       } else {
+        rc = flush();
+        if (rc != NINT_OK) return rc;
         probe.stamp(NINT_PROBE_DGRAD, l, 0, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l], dx_dst, dh_prev, ow, nullptr, stream);
         probe.stamp(NINT_PROBE_DGRAD, l, 0, 1);
@@ -310,6 +353,8 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       if (rc != NINT_OK) return rc;
     }
   }
+  rc = flush();
+  if (rc != NINT_OK) return rc;
   // weight / bias gradients: ONE reduction over all T time steps per layer and source, all layers' folds merged
   WgJob jobs[NINT_MAX_LAYERS];
   for (int l = 0; l < L; ++l) {

@@ -23,8 +23,7 @@ XFOLD = True
 # nint_layer.wide of engines built afterwards: 0 = the library picks the gate / dgrad kernel family per launch shape, 1 = always
 # the 4-wave kernels (csrc/conv_igemm.hip), 2 = the 8-wave LDS-weight kernel (csrc/conv_wide.hip) wherever it is instantiated
 FORCE_WIDE = 0
-FORCE_WAVE = None        # forward (t, layer) wavefront: None = by batch size (SeqEngine._lend_wave), 0 = never, 1 = always
-WAVE_STREAMS = 1          # side streams: layer l >= 1 runs on stream min(l, WAVE_STREAMS) (one side stream measured best: every cross-stream edge costs a marker on the first layer's chain)
+FORCE_WAVE = None        # forward (t, layer) wavefront as one grid per step: None = by batch size (SeqEngine._set_wave), 0 = never, 1 = always
 WAVE_TILES_PER_CU = 3     # ... on while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs
 FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
 
@@ -158,7 +157,6 @@ class SeqEngine:
         self.train_unsupported = self.untrainable_layers(self.cfgs, self.dt, self.n_cu)
         self._wg_bytes = wg_bytes
         self._wg_partial = None
-        self._wave = None                        # side streams / events lent to nint_seq_fwd (created at first use)
         self.pool: Dict[tuple, List[Workspace]] = {}
 
     @property
@@ -247,32 +245,16 @@ class SeqEngine:
                 cc = c0[l].detach().float().contiguous()
                 check(self.lib.nint_pack_compact(ptr(cc), C.c_void_p(ws.c_view(self, l, 0)), B, cfg.Ch, Chp, H, W, NINT_F32, st),
                       "pack c0")
-        self._lend_wave(ws)
+        self._set_wave(ws)
         check(self.lib.nint_seq_fwd(C.byref(ws.seq), st), "nint_seq_fwd")
 
-    def _lend_wave(self, ws: Workspace):
-        """nint_seq.wave: the (t, layer) wavefront of the forward pass on side streams the ENGINE owns (the library owns
-        none).  FORCE_WAVE = None: on for the strong-scaling shape (the first layer's launch leaves CUs without a
-        workgroup: B = 1-2 per GPU at 100 x 154), 0 / 1: off / on."""
-        L = len(self.cfgs)
+    def _set_wave(self, ws: Workspace):
+        """nint_seq.wave: the (t, layer) wavefront of the forward pass, one grid per step.  FORCE_WAVE = None: on for the
+        strong-scaling shape (the first layer's launch leaves CUs without a workgroup: B = 1-2 per GPU at 100 x 154),
+        0 / 1: off / on."""
         tiles8 = ws.B * ((ws.W + 15) // 16) * ((ws.H + 7) // 8)
         on = (2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu) if FORCE_WAVE is None else bool(FORCE_WAVE)
-        on = on and L > 1 and not ws.seq.probe_mask
-        ws.seq.wave = int(on)
-        if not on:
-            return
-        if self._wave is None:
-            streams = [torch.cuda.Stream(device=self.device) for _ in range(min(L - 1, WAVE_STREAMS))]
-            streams += [streams[-1]] * (L - 1 - len(streams))
-            events = [torch.cuda.Event() for _ in range(L + 1)]
-            for e in events:
-                e.record()                       # (torch creates the hipEvent_t at the first record)
-            self._wave = (streams, events)
-        streams, events = self._wave
-        for l in range(L):
-            ws.seq.wave_stream[l] = None if l == 0 else streams[l - 1].cuda_stream
-        for l in range(L + 1):
-            ws.seq.wave_event[l] = events[l].cuda_event
+        ws.seq.wave = int(on and len(self.cfgs) > 1)
 
     def pack_input(self, ws: Workspace, x):
         """Fill the input slab ws.xs (image t*B+b, channels-last ET, folded for thin inputs) from x: a (B,T,C,H,W)

@@ -40,13 +40,13 @@ def test_struct_layout_matches_header(tmp_path):
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nint.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(nint_geom),sizeof(nint_layer),sizeof(nint_seq),offsetof(nint_layer,Wf),offsetof(nint_seq,xs),'
                     'offsetof(nint_seq,dW),offsetof(nint_seq,wg_partial_bytes),offsetof(nint_layer,wide),'
-                    'offsetof(nint_seq,probe),offsetof(nint_seq,probe_slots),offsetof(nint_seq,wave),offsetof(nint_seq,wave_event));return 0;}\n')
+                    'offsetof(nint_seq,probe),offsetof(nint_seq,probe_slots),offsetof(nint_seq,wave),sizeof(nint_seq));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.NintGeom), C.sizeof(_lib.NintLayer), C.sizeof(_lib.NintSeq), _lib.NintLayer.Wf.offset,
             _lib.NintSeq.xs.offset, _lib.NintSeq.dW.offset, _lib.NintSeq.wg_partial_bytes.offset, _lib.NintLayer.wide.offset,
-            _lib.NintSeq.probe.offset, _lib.NintSeq.probe_slots.offset, _lib.NintSeq.wave.offset, _lib.NintSeq.wave_event.offset]
+            _lib.NintSeq.probe.offset, _lib.NintSeq.probe_slots.offset, _lib.NintSeq.wave.offset, C.sizeof(_lib.NintSeq)]
     assert got == want
 
 

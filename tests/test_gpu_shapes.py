@@ -187,25 +187,26 @@ def test_k9_forward_works_and_training_is_refused_early(pkg):
         net(X.cuda())
 
 
-@pytest.mark.parametrize("streams", [1, 2])
-def test_forward_wavefront_on_side_streams_changes_no_bit(pkg, streams):
-    """nint_seq.wave (include/nint.h): the (t, layer) wavefront of the forward pass on streams and events the engine lends
-    -- the same launches in another enqueue order -- gives the serial order's prediction and gradients bit for bit, with
-    one side stream (layers 1.. share it) and with one per layer; the engine's own rule turns it on for B = 1 at the bench
-    grid and off for B = 8."""
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(7, [24, 16, 8], [5, 3, 3], 2, 1, 5, 37, 50), (62, [64, 32, 16], [5, 3, 3], 20, 2, 3, 100, 154),
+                                   (5, [16, 16], [3, 3], 1, 3, 1, 9, 17)])
+def test_forward_wavefront_as_one_grid_per_step_changes_no_bit(pkg, shape, dtype):
+    """nint_seq.wave (include/nint.h): the (t, layer) wavefront of the forward pass, each step's gate launches merged into
+    ONE grid (conv_lstm_multi_kernel) -- the same workgroups on the same data -- gives the time-major order's prediction and
+    gradients bit for bit (small batch at a ragged grid, the bench grid at B = 2, T = 1 with two layers)."""
     from nasa_niswan_amd import engine
-    C, hidden, ks, out, B, T, H, W = 7, [24, 16, 8], [5, 3, 3], 2, 1, 5, 37, 50
+    C, hidden, ks, out, B, T, H, W = shape
     torch.manual_seed(3)
     X = torch.randn(B, T, C, H, W, device="cuda")
     wgt = torch.randn(B, out, H, W, device="cuda")
     res = {}
-    old = engine.FORCE_WAVE, engine.WAVE_STREAMS
+    old = engine.FORCE_WAVE
     try:
         for wave in (0, 1):
-            engine.FORCE_WAVE, engine.WAVE_STREAMS = wave, streams
+            engine.FORCE_WAVE = wave
             torch.manual_seed(4)
-            net = pkg.ConvLSTM(C, hidden, ks, 3, out_channels=out, compute_dtype="bf16").cuda()
-            for rep in range(2):                  # (the second pass reuses the workspace and the lent streams)
+            net = pkg.ConvLSTM(C, hidden, ks, len(hidden), out_channels=out, compute_dtype=dtype).cuda()
+            for rep in range(2):                  # (the second pass reuses the workspace)
                 net.zero_grad()
                 pred = net(X)
                 (pred * wgt).sum().backward()
@@ -213,14 +214,34 @@ def test_forward_wavefront_on_side_streams_changes_no_bit(pkg, streams):
             res[wave] = [pred.detach().clone()] + [p.grad.clone() for p in net.parameters()]
             assert {ws.seq.wave for pool in net._engine(X.device).pool.values() for ws in pool} == {wave}
     finally:
-        engine.FORCE_WAVE, engine.WAVE_STREAMS = old
+        engine.FORCE_WAVE = old
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
-    # the engine's rule (FORCE_WAVE None): B = 1 of the bench grid lends streams, B = 8 does not
+
+
+def test_forward_wavefront_rule_and_fallback(pkg):
+    """The engine's own rule (FORCE_WAVE None) turns the wavefront on for B = 1 at the bench grid and off for B = 8; forced on
+    at B = 8 the first layer keeps its 8-row tiles, which the merged grid does not hold: the steps fall back to one launch
+    per layer -- still the same results."""
+    from nasa_niswan_amd import engine
     assert engine.FORCE_WAVE is None
+    torch.manual_seed(5)
     net = pkg.ConvLSTM(62, [64, 32, 16], [5, 3, 3], 3, out_channels=20, compute_dtype="bf16").cuda()
+    X1, X8 = torch.randn(1, 2, 62, 100, 154, device="cuda"), torch.randn(8, 2, 62, 100, 154, device="cuda")
     with torch.no_grad():
-        p1 = net(torch.randn(1, 2, 62, 100, 154, device="cuda"))
-        p8 = net(torch.randn(8, 2, 62, 100, 154, device="cuda"))
-    assert torch.isfinite(p1).all() and torch.isfinite(p8).all()
+        p1, p8 = net(X1), net(X8)
     assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 1, 8: 0}
+    engine.FORCE_WAVE = 1
+    try:
+        with torch.no_grad():
+            q8 = net(X8)
+    finally:
+        engine.FORCE_WAVE = None
+    assert torch.equal(p8, q8)
+    engine.FORCE_WAVE = 0
+    try:
+        with torch.no_grad():
+            q1 = net(X1)
+    finally:
+        engine.FORCE_WAVE = None
+    assert torch.equal(p1, q1)
