@@ -479,7 +479,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, c
           gf[r] = sigmoidf_(acc[i][cb * 4 + 1][r]);
           gg[r] = tanhf_(acc[i][cb * 4 + 2][r]);
           go[r] = sigmoidf_(acc[i][cb * 4 + 3][r]);
-          cn[r] = cp[r] * gf[r] + gi[r] * gg[r];       // model.py:228
+          cn[r] = fmaf(cp[r], gf[r], gi[r] * gg[r]);   // model.py:228 (the association is pinned: the 4-wave, merged-grid and 8-wave kernels agree bit for bit)
           hn[r] = go[r] * tanhf_(cn[r]);               // model.py:229
         }
         if (ok) {

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_lstm_kernel(WideArgs a) {
           gf[r] = sigmoidf_(acc[i][1][r]);
           gg[r] = tanhf_(acc[i][2][r]);
           go[r] = sigmoidf_(acc[i][3][r]);
-          cn[r] = cp[r] * gf[r] + gi[r] * gg[r];      // model.py:228
+          cn[r] = fmaf(cp[r], gf[r], gi[r] * gg[r]);  // model.py:228 (association pinned as in conv_igemm.hip)
           hn[r] = go[r] * tanhf_(cn[r]);              // model.py:229
         }
         if (ok) {

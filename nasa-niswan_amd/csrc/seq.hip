@@ -167,15 +167,17 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
     for (int w = 0; w < s->T + L - 1; ++w) {
       ConvPlan plans[NINT_MULTI_MAX];
       int lt[NINT_MULTI_MAX][2], n = 0;
-      rc = NINT_OK;
-      for (int l = 0; l < L && rc == NINT_OK; ++l) {
+      for (int l = 0; l < L; ++l) {
         const int t = w - l;
         if (t < 0 || t >= s->T) continue;
-        const CellFwdJob j = job(l, t);
-        rc = nint_internal_cell_fwd_plan(&j, g, s->dtype, B, &plans[n]);
         lt[n][0] = l; lt[n][1] = t; ++n;
       }
-      if (rc == NINT_OK) rc = n > 1 ? nint_internal_conv_multi(plans, n, s->dtype, stream) : NINT_E_SHAPE;
+      rc = n > 1 ? NINT_OK : NINT_E_SHAPE;
+      for (int q = 0; q < n && rc == NINT_OK; ++q) {
+        const CellFwdJob j = job(lt[q][0], lt[q][1]);
+        rc = nint_internal_cell_fwd_plan(&j, g, s->dtype, B, &plans[q]);
+      }
+      if (rc == NINT_OK) rc = nint_internal_conv_multi(plans, n, s->dtype, stream);
       if (rc == NINT_E_SHAPE) {                // a shape the merged grid does not hold (or a single launch): one by one
         for (int q = 0; q < n; ++q) {
           rc = launch(lt[q][0], lt[q][1]);
