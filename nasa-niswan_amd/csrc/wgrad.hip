@@ -454,10 +454,15 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
     const int CW = 16 * w.NTC;
     if (Cp % CW) return NINT_E_SHAPE;
     w.CB = Cp / CW;
-    // two workgroups per CU in flight, but never fewer than 32 pixel tiles per split: the
-    // accumulator flush (J KiB-tiles per workgroup) must stay small against the K work
+    // two workgroups per CU in flight, but never fewer than NINT_WG_MIN_TILES pixel tiles per split: the
+    // accumulator flush (J KiB-tiles per workgroup) must stay small against the K work.  (32 until round 3; at B = 1-2
+    // per GPU that left the narrow layers' launches at 92-276 workgroups: 8 measured +2.9 % on the B = 1 step, +0.9 % at
+    // B = 2, nothing at B >= 4 where the workgroup cap binds first; 4 and 2 equal 8.)
+#ifndef NINT_WG_MIN_TILES
+#define NINT_WG_MIN_TILES 8
+#endif
     int s = nint_cdiv(2 * n_cu, pl->NB * w.CB * w.TG);
-    if (s > pl->ntiles / 32) s = pl->ntiles / 32;
+    if (s > pl->ntiles / NINT_WG_MIN_TILES) s = pl->ntiles / NINT_WG_MIN_TILES;
     if (s < 1) s = 1;
     // re-derive the split count so that no split is empty
     w.splits = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
@@ -468,7 +473,7 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   pl->merged = wx.NTC == wh.NTC && wx.JW == wh.JW && wx.KX == wh.KX && wx.TG == 1 && wh.TG == 1 && pl->NB * (wx.CB + wh.CB) <= 8;
   if (pl->merged) {
     int s = nint_cdiv(2 * n_cu, pl->NB * (wx.CB + wh.CB));
-    if (s > pl->ntiles / 32) s = pl->ntiles / 32;
+    if (s > pl->ntiles / NINT_WG_MIN_TILES) s = pl->ntiles / NINT_WG_MIN_TILES;
     if (s < 1) s = 1;
     s = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
     // a multiple of 8 splits: workgroup (split, column) sits on XCD (split + splits * column) % 8, so all columns of a split
