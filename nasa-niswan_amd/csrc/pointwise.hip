@@ -767,6 +767,95 @@ __global__ __launch_bounds__(512) void head_bwd_dw_tiled_kernel(const void* __re
     if ((int)threadIdx.x + 512 * k < nout) partial[(size_t)blockIdx.x * nout + threadIdx.x + 512 * k] = acc[k];
 }
 
+// Larger heads (more than 512 outputs, and the smaller of O and Ch + 1 at most 32 -- 200 outputs x 16 channels, or 20 x
+// 128): REGISTER-tiled.  The smaller dimension ("R") lives in registers, a thread owns one index of the larger one ("T")
+// and NH = 512 / T pixel strides: per staged pixel it reads its own T value once and the R values as broadcast 16-byte reads
+// -- 1 + R/4 LDS instructions per R FMAs instead of 2 per FMA.  The NH partial sums of an output are folded through LDS in
+// fixed order; the slab layout is head_bwd_dw_tiled_kernel's.
+template <int DT>
+__global__ __launch_bounds__(512) void head_bwd_dw_rtile_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp,
+                                                              int O, const float* __restrict__ dpred,
+                                                              float* __restrict__ partial, int H, int W, int P, int Hh,
+                                                              int Wh, int stage) {
+  extern __shared__ __attribute__((aligned(16))) float smem_dw[];
+  const int C1 = Ch + 1;
+  const bool r_is_c = C1 <= O;                 // registers over the channels (+ bias), threads over the outputs -- or the other way round
+  const int R = r_is_c ? C1 : O, T = r_is_c ? O : C1;
+  const int SR = (R + 3) & ~3, ST = T | 1;     // row strides: 16-byte rows for the broadcast reads, odd for the per-thread ones
+  float* sr = smem_dw;                         // [pixel][R]
+  float* st = smem_dw + stage * SR;            // [pixel][T]
+  float* sd = r_is_c ? st : sr;                // dpred [pixel][o]
+  float* sh = r_is_c ? sr : st;                // h     [pixel][c] + 1
+  const int SD = r_is_c ? ST : SR, SH = r_is_c ? SR : ST;
+  const int nout = O * C1;
+  const int NH = min(8, 512 / T);
+  const int ti = threadIdx.x % T, hf = threadIdx.x / T;
+  const bool act = hf < NH;
+  float acc[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) acc[r] = 0.f;
+  const size_t npix = (size_t)N * H * W;
+  const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  const int nq = (Ch + 3) / 4;
+  for (size_t base = p0; base < p1; base += stage) {
+    const int cnt = (int)min((size_t)stage, p1 - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt * O; i += 512) {        // dpred planes: consecutive threads walk consecutive pixels
+      const int oo = i / cnt, pp = i - oo * cnt;
+      const size_t pix = base + pp;
+      const size_t yx = pix % ((size_t)H * W);
+      const size_t n = pix / ((size_t)H * W);
+      sd[pp * SD + oo] = dpred[(n * O + oo) * (size_t)H * W + yx];
+    }
+    for (int i = threadIdx.x; i < cnt * nq; i += 512) {       // h: one 4-channel vector per thread
+      const int pp = i / nq, q = i - pp * nq;
+      const size_t pix = base + pp;
+      const int x = pix % W;
+      size_t r = pix / W;
+      const int y = r % H;
+      const int n = r / H;
+      const f32x4_t v = load_vec4<DT>(h, ((((size_t)(n0 + n)) * Hh + (y + P)) * Wh + (x + P)) * Chp + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < Ch) sh[pp * SH + 4 * q + e] = v[e];
+      if (q == 0) sh[pp * SH + Ch] = 1.f;
+    }
+    if (SR > R) for (int i = threadIdx.x; i < cnt; i += 512)   // the tail of the 16-byte rows feeds accumulators that are never stored: keep it finite
+      for (int r = R; r < SR; ++r) sr[i * SR + r] = 0.f;
+    __syncthreads();
+    if (act) {
+      for (int pp = hf; pp < cnt; pp += NH) {
+        const float tv = st[pp * ST + ti];
+        const f32x4_t* rr = (const f32x4_t*)(sr + pp * SR);
+#pragma unroll
+        for (int r4 = 0; r4 < 8; ++r4) {
+          if (4 * r4 < SR) {
+            const f32x4_t rv = rr[r4];
+            acc[4 * r4] += tv * rv[0]; acc[4 * r4 + 1] += tv * rv[1]; acc[4 * r4 + 2] += tv * rv[2]; acc[4 * r4 + 3] += tv * rv[3];
+          }
+        }
+      }
+    }
+  }
+  // fold the NH pixel strides of every output (fixed order) through LDS: red[hf][ti][r]
+  __syncthreads();
+  float* red = smem_dw;                        // NH * T * SR floats (the launch reserves the larger of this and the staging buffers)
+  if (act) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+      if (r < R) red[((size_t)hf * T + ti) * SR + r] = acc[r];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nout; i += 512) {
+    const int o = i / C1, c = i - o * C1;
+    const int t2 = r_is_c ? o : c, r2 = r_is_c ? c : o;
+    float s = 0.f;
+    for (int q = 0; q < NH; ++q) s += red[((size_t)q * T + t2) * SR + r2];
+    partial[(size_t)blockIdx.x * nout + i] = s;
+  }
+}
+
 // block = 64 outputs x blockDim/64 lanes over the per-workgroup partials; fixed order
 __global__ void head_bwd_dw_final_kernel(const float* __restrict__ partial, int nblocks, int Ch, int O,
                                          float* __restrict__ dw, float* __restrict__ db) {
@@ -839,6 +928,28 @@ extern "C" int nint_head_bwd(const void* h_slab, int n0, int N, int Ch, int Chp,
   }
   const int nout = O * (Ch + 1);
   const int row_floats = (O | 1) + ((Ch + 1) | 1);
+  const int Rd = O < Ch + 1 ? O : Ch + 1, Td = O < Ch + 1 ? Ch + 1 : O;      // register / thread dimension of the register-tiled kernel
+  if (dw && db && scratch && nout > 512 && Rd <= 32 && Td <= 512 && scratch_bytes >= (size_t)256 * nout * sizeof(float)) {
+    const int SR = (Rd + 3) & ~3, ST = Td | 1, NH = 512 / Td < 8 ? 512 / Td : 8;
+    int stage = HEAD_DW_LDS_FLOATS / (SR + ST);
+    if (stage > HEAD_DW_PIX) stage = HEAD_DW_PIX;
+    size_t lds_f = (size_t)stage * (SR + ST);
+    if ((size_t)NH * Td * SR > lds_f) lds_f = (size_t)NH * Td * SR;            // the closing fold's buffer
+    const size_t lds = lds_f * sizeof(float);
+    if (stage >= 8 && lds <= 64 * 1024) {
+      const size_t cap = scratch_bytes / ((size_t)nout * sizeof(float));
+      const size_t want = (npix + HEAD_DW_PIX - 1) / HEAD_DW_PIX;
+      const int nblk = (int)(want < cap ? want : cap);
+      if (dtype == NINT_BF16)
+        hipLaunchKernelGGL(head_bwd_dw_rtile_kernel<NINT_BF16>, dim3(nblk), dim3(512), lds, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh, stage);
+      else
+        hipLaunchKernelGGL(head_bwd_dw_rtile_kernel<NINT_F32>, dim3(nblk), dim3(512), lds, st, h_slab, n0, N, Ch, Chp, O, dpred, scratch, g->H, g->W, g->P, g->Hh, g->Wh, stage);
+      NINT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(nint_cdiv(nout, 64)), dim3(1024), 0, st, scratch, nblk, Ch, O, dw, db);
+      NINT_LAUNCH_CHECK();
+      return NINT_OK;
+    }
+  }
   if (dw && db && scratch && nout <= HEAD_DW_NK * 512 && 8 * row_floats <= HEAD_DW_LDS_FLOATS &&
       scratch_bytes >= (size_t)256 * nout * sizeof(float)) {
     int stage = HEAD_DW_LDS_FLOATS / row_floats;               // pixels staged at a time (60 KiB of LDS)
@@ -958,6 +1069,7 @@ extern "C" int nint_loss_mse_l1_crop(const float* pred, const float* y, float* d
 // partial sums (train.py:102,105), d loss / d pred, and dL/dh = w^T . dpred.  One thread per pixel (grid-stride):
 // the channel vector is read once, pred never goes to memory, dpred is written for the head's weight gradient.
 // Same arithmetic, in the same order, as head_fwd_kernel -> loss_partial_kernel -> head_bwd_dh_kernel.
+#define HEAD_OCH 64
 template <int DT, int CHV>
 __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __restrict__ h, int n0, int N, int Ch, int Chp, int O,
                                                               const float* __restrict__ w, const float* __restrict__ b,
@@ -970,13 +1082,12 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
   // the first version -- is a chain of O dependent round trips on 1/4 of the threads: 50 us at B = 8, 44 us at B = 1.)
   extern __shared__ __attribute__((aligned(16))) char smem_hl[];
   float* w_s = (float*)smem_hl;                  // [O][CHV], zero padded (head_stage_weights)
-  float* gq_s = w_s + O * CHV;                   // [O][64]
+  float* gq_s = w_s + O * CHV;                   // [min(O, HEAD_OCH)][64]
   head_stage_weights<CHV>(w_s, w, O, Ch);
   const int lane = threadIdx.x & 63;
   const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the weight reads below stay scalar loads)
   const size_t npix = (size_t)N * H * W;
   const double inv_n = 1.0 / ((double)N * O * Hc * Wc);
-  const int OG = (O + 3) / 4, ob = q * OG, oe = min(O, ob + OG);
   constexpr int CQ = CHV / 4;                    // channels per wave in phase 2
   double s2 = 0, s1 = 0, sy = 0, syy = 0;
   for (size_t p0 = (size_t)blockIdx.x * 64; p0 < npix; p0 += (size_t)gridDim.x * 64) {
@@ -998,49 +1109,56 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const void* __rest
     const bool in = live && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
     float* dp = dpred + ((size_t)n * O * H + yy) * W + x;
     const float* yp = y + ((size_t)n * O * Hc + cy) * Wc + cx;
-    constexpr int OU = 5;                        // targets fetched ahead of their use: one HBM round trip per OU outputs
-    for (int o0 = ob; o0 < oe; o0 += OU) {
-      float tq[OU];
-#pragma unroll
-      for (int u = 0; u < OU; ++u) tq[u] = (in && o0 + u < oe) ? yp[(size_t)(o0 + u) * Hc * Wc] : 0.f;
-#pragma unroll
-      for (int u = 0; u < OU; ++u) {
-        const int o = o0 + u;
-        if (o >= oe) break;
-        float p = b ? b[o] : 0.f;
-        const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV);
-#pragma unroll
-        for (int c = 0; c < CHV; c += 4) {
-          const f32x4_t wv = wr[c / 4];
-          p += wv[0] * hv[c]; p += wv[1] * hv[c + 1]; p += wv[2] * hv[c + 2]; p += wv[3] * hv[c + 3];
-        }
-        float gq = 0.f;
-        if (in) {
-          const float t = tq[u];
-          const float d = p - t;
-          s2 += (double)d * d;
-          s1 += fabs((double)d);
-          sy += t;
-          syy += (double)t * t;
-          gq = (float)((2.0 * d + (d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0))) * inv_n);
-        }
-        if (live) dp[(size_t)o * H * W] = gq;
-        gq_s[o * 64 + lane] = gq;
-      }
-    }
-    __syncthreads();
-    // phase 2: dL/dh[c] = sum_o w[o][c] * gq[o], in output order (the order of head_bwd_dh_kernel)
     float acc[CQ];
 #pragma unroll
     for (int c = 0; c < CQ; ++c) acc[c] = 0.f;
     const int c0 = q * CQ;
-    for (int o = 0; o < O; ++o) {
-      const float gq = gq_s[o * 64 + lane];
-      const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV + c0);
+    // the outputs in chunks of HEAD_OCH (d loss / d pred of one chunk in LDS at a time: 200 outputs would otherwise pin the
+    // workgroup count per CU at one); phase 2 keeps accumulating in output order across the chunks
+    for (int oc = 0; oc < O; oc += HEAD_OCH) {
+      const int on = min(HEAD_OCH, O - oc);
+      const int OG = (on + 3) / 4, ob = oc + q * OG, oe = min(oc + on, ob + OG);
+      if (oc > 0) __syncthreads();               // the previous chunk is consumed
+      constexpr int OU = 5;                      // targets fetched ahead of their use: one HBM round trip per OU outputs
+      for (int o0 = ob; o0 < oe; o0 += OU) {
+        float tq[OU];
 #pragma unroll
-      for (int c = 0; c < CQ; c += 4) {
-        const f32x4_t wv = wr[c / 4];
-        acc[c] += wv[0] * gq; acc[c + 1] += wv[1] * gq; acc[c + 2] += wv[2] * gq; acc[c + 3] += wv[3] * gq;
+        for (int u = 0; u < OU; ++u) tq[u] = (in && o0 + u < oe) ? yp[(size_t)(o0 + u) * Hc * Wc] : 0.f;
+#pragma unroll
+        for (int u = 0; u < OU; ++u) {
+          const int o = o0 + u;
+          if (o >= oe) break;
+          float p = b ? b[o] : 0.f;
+          const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV);
+#pragma unroll
+          for (int c = 0; c < CHV; c += 4) {
+            const f32x4_t wv = wr[c / 4];
+            p += wv[0] * hv[c]; p += wv[1] * hv[c + 1]; p += wv[2] * hv[c + 2]; p += wv[3] * hv[c + 3];
+          }
+          float gq = 0.f;
+          if (in) {
+            const float t = tq[u];
+            const float d = p - t;
+            s2 += (double)d * d;
+            s1 += fabs((double)d);
+            sy += t;
+            syy += (double)t * t;
+            gq = (float)((2.0 * d + (d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0))) * inv_n);
+          }
+          if (live) dp[(size_t)o * H * W] = gq;
+          gq_s[(o - oc) * 64 + lane] = gq;
+        }
+      }
+      __syncthreads();
+      // phase 2: dL/dh[c] = sum_o w[o][c] * gq[o], in output order (the order of head_bwd_dh_kernel)
+      for (int o = oc; o < oc + on; ++o) {
+        const float gq = gq_s[(o - oc) * 64 + lane];
+        const f32x4_t* wr = (const f32x4_t*)(w_s + o * CHV + c0);
+#pragma unroll
+        for (int c = 0; c < CQ; c += 4) {
+          const f32x4_t wv = wr[c / 4];
+          acc[c] += wv[0] * gq; acc[c + 1] += wv[1] * gq; acc[c + 2] += wv[2] * gq; acc[c + 3] += wv[3] * gq;
+        }
       }
     }
     if (live) {
@@ -1076,7 +1194,7 @@ extern "C" int nint_head_loss_fused(const void* h_slab, int n0, int N, int Ch, i
   const int nblk = (int)((npix + 63) / 64 < LOSS_BLOCKS_MAX ? (npix + 63) / 64 : LOSS_BLOCKS_MAX);
   const dim3 grid(nblk);
   const int chv = Chp <= 32 ? 32 : (Chp <= 64 ? 64 : 128);
-  const size_t lds = (size_t)O * (chv + 64) * sizeof(float);      // weights [O][CHV] + d loss / d pred of 64 pixels [O][64]
+  const size_t lds = ((size_t)O * chv + (size_t)(O < HEAD_OCH ? O : HEAD_OCH) * 64) * sizeof(float);   // weights [O][CHV] + d loss / d pred of 64 pixels, one output chunk
   if (lds + 8192 > 160 * 1024) return NINT_E_SHAPE;
 #define NINT_HL(DT_, CHV_) { auto kern = head_loss_fused_kernel<DT_, CHV_>;                                                                   \
                              if (lds + 8192 > 64 * 1024) NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \

@@ -314,7 +314,7 @@ class SeqEngine:
         Chp = cfg.padded(self.kc)[2]
         O = w.shape[0]
         chv = 32 if Chp <= 32 else (64 if Chp <= 64 else 128)
-        if Chp > 128 or O * (chv + 64) * 4 + 8192 > 160 * 1024:
+        if Chp > 128 or (O * chv + min(O, 64) * 64) * 4 + 8192 > 160 * 1024:
             return False
         w2 = w.detach().float().contiguous()
         b2 = None if b is None else b.detach().float().contiguous()
