@@ -189,11 +189,13 @@ def test_k9_forward_works_and_training_is_refused_early(pkg):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("shape", [(7, [24, 16, 8], [5, 3, 3], 2, 1, 5, 37, 50), (62, [64, 32, 16], [5, 3, 3], 20, 2, 3, 100, 154),
-                                   (5, [16, 16], [3, 3], 1, 3, 1, 9, 17)])
+                                   (5, [16, 16], [3, 3], 1, 3, 1, 9, 17), (6, [16, 16, 8, 8], [3, 3, 3, 3], 1, 2, 3, 21, 40),
+                                   (6, [8, 8, 8, 8, 8], [3, 3, 3, 3, 3], 1, 1, 3, 12, 20)])
 def test_forward_wavefront_as_one_grid_per_step_changes_no_bit(pkg, shape, dtype):
     """nint_seq.wave (include/nint.h): the (t, layer) wavefront of the forward pass, each step's gate launches merged into
     ONE grid (conv_lstm_multi_kernel) -- the same workgroups on the same data -- gives the time-major order's prediction and
-    gradients bit for bit (small batch at a ragged grid, the bench grid at B = 2, T = 1 with two layers)."""
+    gradients bit for bit (small batch at a ragged grid, the bench grid at B = 2, T = 1 with two layers, four layers = the
+    merged kernels' limit, five layers = one launch per layer again)."""
     from nasa_niswan_amd import engine
     C, hidden, ks, out, B, T, H, W = shape
     torch.manual_seed(3)
