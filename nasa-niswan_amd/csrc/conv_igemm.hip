@@ -710,6 +710,22 @@ __global__ __launch_bounds__(256, 3) void conv_lstm_multi_kernel(ConvMulti m) {
     default: break;
   }
 }
+// ... with the first layer on its 8-row tiles (mid-size batches; 256 registers: two workgroups per CU for every problem of
+// the grid).  B = 4 at 100 x 154: 966 -> 989 samples/s, steady; B = 8: bimodal from process to process (1021-1032 or 995-1000
+// against a steady 1022-1025), so the engine's rule stops below it.
+#define NINT_MULTI_CASE8(EPI_, WN_, WK_, NTW_) \
+  case conv_variant(EPI_, WN_, WK_, NTW_, 8): conv_igemm_body<DT, EPI_, WN_, WK_, NTW_, 8>(a, smem, bx, by, nbx); break;
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_lstm_multi8_kernel(ConvMulti m) {
+  NINT_MULTI_PROLOGUE
+  switch (m.variant[i]) {
+    NINT_MULTI_CASE8(EPI_LSTM, 4, 1, 4)
+    NINT_MULTI_CASE(EPI_LSTM, 4, 1, 4)
+    NINT_MULTI_CASE(EPI_LSTM, 2, 2, 4)
+    NINT_MULTI_CASE(EPI_LSTM, 1, 4, 4)
+    default: break;
+  }
+}
 template <int DT>
 __global__ __launch_bounds__(256, 3) void conv_bwd_multi_kernel(ConvMulti m) {
   NINT_MULTI_PROLOGUE
@@ -720,8 +736,20 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_multi_kernel(ConvMulti m) {
     default: break;                            // (the register-heavy fused shapes -- 4 column tiles per wave -- would spill at 168 VGPRs)
   }
 }
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_bwd_multi8_kernel(ConvMulti m) {
+  NINT_MULTI_PROLOGUE
+  switch (m.variant[i]) {
+    NINT_MULTI_CASE8(EPI_DGRAD, 1, 4, 4)
+    NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 4)
+    NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 2)
+    NINT_MULTI_CASE(EPI_DGRAD_PW, 1, 4, 3)
+    default: break;
+  }
+}
 static bool multi_holds(int variant) {
   switch (variant) {
+    case conv_variant(EPI_LSTM, 4, 1, 4, 8): case conv_variant(EPI_DGRAD, 1, 4, 4, 8):      // (the *_multi8 kernels)
     case conv_variant(EPI_LSTM, 4, 1, 4, 4): case conv_variant(EPI_LSTM, 2, 2, 4, 4): case conv_variant(EPI_LSTM, 1, 4, 4, 4):
     case conv_variant(EPI_DGRAD, 1, 4, 4, 4): case conv_variant(EPI_DGRAD, 1, 4, 2, 4): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 4):
       return true;
@@ -907,7 +935,11 @@ int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stre
   { auto kern = KERN_;                                                                                                                \
     if (lds > 64 * 1024) NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(kern, dim3(b), dim3(256), lds, st, m); }
-  if (nfwd) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_F32>) }
+  bool rows8 = false;
+  for (int i = 0; i < n; ++i) rows8 = rows8 || plans[i].variant % 10 == 2;
+  if (nfwd && rows8) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_F32>) }
+  else if (nfwd) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_F32>) }
+  else if (rows8) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_bwd_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_bwd_multi8_kernel<NINT_F32>) }
   else { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_bwd_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_bwd_multi_kernel<NINT_F32>) }
 #undef NINT_MULTI_LAUNCH
   NINT_LAUNCH_CHECK();

@@ -24,7 +24,7 @@ XFOLD = True
 # the 4-wave kernels (csrc/conv_igemm.hip), 2 = the 8-wave LDS-weight kernel (csrc/conv_wide.hip) wherever it is instantiated
 FORCE_WIDE = 0
 FORCE_WAVE = None        # forward (t, layer) wavefront as one grid per step: None = by batch size (SeqEngine._set_wave), 0 = never, 1 = always
-WAVE_TILES_PER_CU = 3     # ... on while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs
+WAVE_TILES_PER_CU = 5     # ... on while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs
 FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
 
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
@@ -249,9 +249,9 @@ class SeqEngine:
         check(self.lib.nint_seq_fwd(C.byref(ws.seq), st), "nint_seq_fwd")
 
     def _set_wave(self, ws: Workspace):
-        """nint_seq.wave: the (t, layer) wavefront of the forward pass, one grid per step.  FORCE_WAVE = None: on for the
-        strong-scaling shape (the first layer's launch leaves CUs without a workgroup: B = 1-2 per GPU at 100 x 154),
-        0 / 1: off / on."""
+        """nint_seq.wave: independent launches (a forward wavefront step; the bottom dgrad with the top layer's fused BPTT
+        step) as one grid.  FORCE_WAVE = None: on for the strong-scaling shapes (up to ~2.5 eight-row pixel tiles per CU:
+        B <= 5 per GPU at 100 x 154; measured +10 / +7 / +2 % at B = 1 / 2 / 4, bimodal at B = 8), 0 / 1: off / on."""
         tiles8 = ws.B * ((ws.W + 15) // 16) * ((ws.H + 7) // 8)
         on = (2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu) if FORCE_WAVE is None else bool(FORCE_WAVE)
         ws.seq.wave = int(on and len(self.cfgs) > 1)

@@ -188,7 +188,7 @@ def test_k9_forward_works_and_training_is_refused_early(pkg):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
-@pytest.mark.parametrize("shape", [(7, [24, 16, 8], [5, 3, 3], 2, 1, 5, 37, 50), (62, [64, 32, 16], [5, 3, 3], 20, 2, 3, 100, 154),
+@pytest.mark.parametrize("shape", [(7, [24, 16, 8], [5, 3, 3], 2, 1, 5, 37, 50), (62, [64, 32, 16], [5, 3, 3], 20, 2, 3, 100, 154), (62, [64, 32, 16], [5, 3, 3], 20, 4, 2, 100, 154),
                                    (5, [16, 16], [3, 3], 1, 3, 1, 9, 17), (6, [16, 16, 8, 8], [3, 3, 3, 3], 1, 2, 3, 21, 40),
                                    (6, [8, 8, 8, 8, 8], [3, 3, 3, 3, 3], 1, 1, 3, 12, 20)])
 def test_forward_wavefront_as_one_grid_per_step_changes_no_bit(pkg, shape, dtype):
@@ -222,17 +222,16 @@ def test_forward_wavefront_as_one_grid_per_step_changes_no_bit(pkg, shape, dtype
 
 
 def test_forward_wavefront_rule_and_fallback(pkg):
-    """The engine's own rule (FORCE_WAVE None) turns the wavefront on for B = 1 at the bench grid and off for B = 8; forced on
-    at B = 8 the first layer keeps its 8-row tiles, which the merged grid does not hold: the steps fall back to one launch
-    per layer -- still the same results."""
+    """The engine's own rule (FORCE_WAVE None) turns the merged grids on for B = 1 and B = 4 at the bench grid (B = 4: the
+    first layer on 8-row tiles, the *_multi8 kernels) and off for B = 8; forced on / off the results are the same bit for bit."""
     from nasa_niswan_amd import engine
     assert engine.FORCE_WAVE is None
     torch.manual_seed(5)
     net = pkg.ConvLSTM(62, [64, 32, 16], [5, 3, 3], 3, out_channels=20, compute_dtype="bf16").cuda()
-    X1, X8 = torch.randn(1, 2, 62, 100, 154, device="cuda"), torch.randn(8, 2, 62, 100, 154, device="cuda")
+    X1, X4, X8 = (torch.randn(b, 2, 62, 100, 154, device="cuda") for b in (1, 4, 8))
     with torch.no_grad():
-        p1, p8 = net(X1), net(X8)
-    assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 1, 8: 0}
+        p1, p4, p8 = net(X1), net(X4), net(X8)
+    assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 1, 4: 1, 8: 0}
     engine.FORCE_WAVE = 1
     try:
         with torch.no_grad():
@@ -243,7 +242,7 @@ def test_forward_wavefront_rule_and_fallback(pkg):
     engine.FORCE_WAVE = 0
     try:
         with torch.no_grad():
-            q1 = net(X1)
+            q1, q4 = net(X1), net(X4)
     finally:
         engine.FORCE_WAVE = None
-    assert torch.equal(p1, q1)
+    assert torch.equal(p1, q1) and torch.equal(p4, q4)
