@@ -458,3 +458,57 @@ def test_thin_inputs_plain_layout_keeps_parity(pkg, dtype):
             check(run_case(pkg, 7, [24, 16], [3, 5], 1, 3, 2, 11, 19, dtype), dtype)          # ragged grid, odd channels
         finally:
             engine.XFOLD = True
+
+
+def _ddp_rank(rank, world, port, out):
+    """One rank of test_two_ranks_on_one_device_match_the_global_batch: gloo process group (it moves the device bucket through
+    the host -- RCCL needs one device per rank), both ranks on cuda:0."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nasa_niswan_amd as p
+    from nasa_niswan_amd.trainer import FusedTrainer
+    from nasa_niswan_amd.utils import shard_indices
+    torch.manual_seed(100 + rank)                     # deliberately different init per rank: the trainer broadcasts rank 0's
+    net = p.ConvLSTM(6, [16, 8], [3, 3], 2, out_channels=2, compute_dtype="f32").cuda()
+    tr = FusedTrainer(net, lr=1e-2, halo=(2, 2))
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(4, 3, 6, 20, 28, generator=g)
+    y = torch.randn(4, 2, 16, 24, generator=g)
+    losses = []
+    for step in range(3):
+        idx = shard_indices(4, step, rank, world, 2, shuffle=False)[0]
+        losses.append(float(tr.step(X[idx].cuda(), y[idx].cuda())))
+    torch.cuda.synchronize()
+    torch.save({"w": tr.flat.data.detach().cpu(), "losses": losses}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_device_match_the_global_batch(pkg, tmp_path):
+    """The N > 1 step on the HIP path (FusedTrainer: bucket broadcast, ONE all-reduce of the flat gradient bucket, 1/world in
+    nint_adam_flat), two ranks sharing this box's one device: after three steps both ranks hold identical weights, and they
+    are the weights of a single process that trained on the global batch (mean of equal shards' gradients = global gradient)."""
+    import socket
+    import torch.multiprocessing as mp
+    from nasa_niswan_amd.trainer import FusedTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "ddp")
+    mp.spawn(_ddp_rank, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["w"], r1["w"])
+    # single process, global batch, rank 0's initial weights (seed 100)
+    torch.manual_seed(100)
+    net = pkg.ConvLSTM(6, [16, 8], [3, 3], 2, out_channels=2, compute_dtype="f32").cuda()
+    tr = FusedTrainer(net, lr=1e-2, halo=(2, 2))
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(4, 3, 6, 20, 28, generator=g)
+    y = torch.randn(4, 2, 16, 24, generator=g)
+    losses = [float(tr.step(X.cuda(), y.cuda())) for _ in range(3)]
+    w = tr.flat.data.detach().cpu()
+    err = float((w - r0["w"]).abs().max() / w.abs().max())
+    print(f"  two ranks vs global batch: weights rel max err {err:.2e}; losses {losses} vs mean of shards "
+          f"{[(a + b) / 2 for a, b in zip(r0['losses'], r1['losses'])]}")
+    assert err < 2e-5
+    for a, b, c in zip(losses, r0["losses"], r1["losses"]):
+        assert abs(a - (b + c) / 2) < 1e-5 * abs(a)
