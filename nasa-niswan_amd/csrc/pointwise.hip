@@ -52,7 +52,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, int
   constexpr int U = VW == 4 ? 4 : 8;
   const int WV = W / VW, total = C * WV;
   const unsigned magic = (unsigned)(((1ull << 32) + WV - 1) / WV);   // idx / WV by multiply-high: exact for idx < 65536, WV <= 4096
-  const bool small = total < 65536 && WV <= 4096;
+  const bool small = total < 65536 && WV <= 4096 && WV > 1;           // (a divisor of 1 has no 32-bit magic number: 2^32)
   for (int base = threadIdx.x; base < total; base += 256 * U) {
     V v[U];
     RowDesc d[U];
@@ -105,7 +105,7 @@ __device__ __forceinline__ void write_row_channels_last(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         const int co = v * V + j;
-        const int kx = (int)__umulhi((unsigned)co, magic_c), c = co - kx * C;
+        const int kx = C == 1 ? co : (int)__umulhi((unsigned)co, magic_c), c = co - kx * C;   // (C = 1: the magic number would be 2^32)
         const int xi = xo + kx - (kf >> 1);
         f[j] = (kx < kf && xi >= 0 && xi < Wo) ? tile[c * ld + xmap(xi)] : 0.f;
       }

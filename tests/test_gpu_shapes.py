@@ -66,6 +66,10 @@ CASES = {
     # opt-in LDS size) on a 1-degree-wide grid, and 180 KiB (> the CU's LDS: per-element pack path) for 100 channels x 450
     "folded-65-channels-wide-grid": (65, [16], [3], 1, 1, 2, 9, 298),
     "folded-100-channels-450-wide": (100, [16], [3], 1, 1, 1, 8, 450),
+    # ONE input channel, folded (channel = kx): the fold's co / C by multiply-high has no 32-bit magic number for C = 1
+    # (found by tools/fuzz_shapes.py: the pack kernel read rows past its tile)
+    "single-input-channel-k5": (1, [32, 16], [5, 3], 1, 2, 2, 8, 49),
+    "single-input-channel-k3-one-column-vectors": (1, [8], [3], 2, 1, 2, 6, 4),
 }
 
 

@@ -31,12 +31,13 @@ def geom(lib, H, W, Pd):
     return g
 
 
+@pytest.mark.parametrize("Cc,W", [(5, 37), (1, 37), (1, 4), (3, 8)])
 @pytest.mark.parametrize("dt", [0, 1])
-def test_xfold_pack_and_its_adjoint(lib, dt):
+def test_xfold_pack_and_its_adjoint(lib, dt, Cc, W):
     """nint_layer.xfold layout: slab channel kx*C + c of pixel x holds input channel c of pixel x + kx - k//2, zero
     outside the image (the convolution's own zero padding); nint_unfold_dx is the adjoint of that fold (what the
     input gradient of a folded first layer needs)."""
-    B, T, Cc, H, W, Pd, k = 2, 2, 5, 9, 37, 2, 5
+    B, T, H, Pd, k = 2, 2, 9, 2, 5          # (one input channel / one vector per row: divisors of 1 in the kernels' index math)
     g = geom(lib, H, W, Pd)
     kc = lib.nint_kc(dt)
     Cp = (k * Cc + kc - 1) // kc * kc

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Random-shape screen of the whole sequence path against the CPU oracle (prediction, all gradients, input gradient):
+layer counts 1-4, kernel sizes 1/3/5/7, ragged grids, thin and thick channel counts, B = 1-5, T = 1-4, both storage types,
+the merged-grid launches forced on and off, both tile heights and the library's choice.
+    python tools/fuzz_shapes.py [--n 40] [--seed 0]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nasa_niswan_amd as pkg  # noqa: E402
+from nasa_niswan_amd import engine  # noqa: E402
+from oracle import convlstm_oracle as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    pkg.load_library()
+    rng = np.random.default_rng(args.seed)
+    worst = {"f32": 0.0, "bf16": 0.0}
+    for it in range(args.n):
+        L = int(rng.integers(1, 5))
+        hidden = [int(rng.choice([4, 8, 16, 24, 32, 48, 64])) for _ in range(L)]
+        ks = [int(rng.choice([1, 3, 3, 5, 5, 7])) for _ in range(L)]
+        C = int(rng.choice([1, 3, 5, 7, 16, 33, 62]))
+        out = int(rng.choice([1, 2, 5, 20]))
+        B, T = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        H, W = int(rng.integers(5, 40)), int(rng.integers(9, 70))
+        dtype = "f32" if it % 2 == 0 else "bf16"
+        engine.FORCE_WAVE = [None, 0, 1][it % 3]
+        engine.FORCE_TILE_ROWS = [0, 0, 4, 8][it % 4]
+        tag = f"#{it} C={C} hidden={hidden} k={ks} out={out} B={B} T={T} {H}x{W} {dtype} wave={engine.FORCE_WAVE} rows={engine.FORCE_TILE_ROWS}"
+        try:
+            params = O.synth_params(C, hidden, ks, L, out_channels=out, seed=it)
+            X = torch.from_numpy(rng.standard_normal((B, T, C, H, W)).astype(np.float32))
+            wgt = torch.from_numpy(rng.standard_normal((B, out, H, W)).astype(np.float32))
+            net = pkg.ConvLSTM(C, hidden, ks, L, out_channels=out, compute_dtype=dtype).cuda()
+            net.load_state_dict(params)
+            Xd = X.cuda().requires_grad_(True)
+            pred = net(Xd)
+            (pred * wgt.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            Xo = X.clone().requires_grad_(True)
+            po = O.convlstm_forward(Xo, leaf)
+            (po * wgt).sum().backward()
+            res = {"pred": (pred.detach().cpu(), po.detach()), "dX": (Xd.grad.cpu(), Xo.grad)}
+            for k, p in net.named_parameters():
+                res["grad." + k] = (p.grad.cpu(), leaf[k].grad)
+            w = 0.0
+            for k, (a, b) in res.items():
+                a, b = a.double(), b.double()
+                assert torch.isfinite(a).all(), (tag, k)
+                if dtype == "f32":
+                    e = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+                    assert e <= 1e-3, (tag, k, e)
+                else:
+                    e = float((a - b).norm() / (b.norm() + 1e-30))
+                    assert e <= 3e-2, (tag, k, e)
+                w = max(w, e)
+            worst[dtype] = max(worst[dtype], w)
+            print(f"ok   {tag}  worst {w:.2e}", flush=True)
+        finally:
+            engine.FORCE_WAVE, engine.FORCE_TILE_ROWS = None, 0
+    print(f"{args.n} shapes ok; worst f32 max-rel {worst['f32']:.2e}, worst bf16 rel-L2 {worst['bf16']:.2e}")
+
+
+if __name__ == "__main__":
+    main()
