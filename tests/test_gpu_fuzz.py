@@ -1,6 +1,7 @@
 """A bounded run of the random-shape screen (tools/fuzz_shapes.py: layer counts 1-4, kernel sizes 1-7, ragged grids, 1-62 input
 channels, B = 1-5, T = 1-4, both storage types, merged-grid launches on / off, both tile heights) against the CPU oracle:
-the module / autograd path, the fused trainer path and the single cell with a given state.  Seeds are fixed; the tool itself takes any seed.  (It found the
+the module / autograd path, the fused trainer path, the single cell with a given state, and the device preproc of a
+resident record (as a batch tensor and straight into the model's input slab).  Seeds are fixed; the tool itself takes any seed.  (It found the
 one-input-channel fold bug of round 3.)"""
 import os
 import subprocess
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [["--n", "30", "--seed", "11"], ["--n", "16", "--seed", "12", "--trainer"], ["--n", "24", "--seed", "13", "--cell"]])
+@pytest.mark.parametrize("extra", [["--n", "30", "--seed", "11"], ["--n", "16", "--seed", "12", "--trainer"], ["--n", "24", "--seed", "13", "--cell"], ["--n", "24", "--seed", "14", "--dataset"]])
 def test_random_shapes_against_the_oracle(extra):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dataset", action="store_true", help="the device preproc (z-score, level fusion, cyclic / reflect halo padding) of a resident synthetic record, as a batch tensor and through the model's input slab, against oracle/preproc_oracle.py instead")
     ap.add_argument("--cell", action="store_true", help="ConvLSTMCell(x, h, c) with a given state (forward, all five gradients) against oracle.cell_forward instead")
     ap.add_argument("--trainer", action="store_true", help="FusedTrainer.step (fused head / loss pass, flat gradient bucket) against oracle.train_step instead")
     args = ap.parse_args()
@@ -39,6 +40,41 @@ def main():
         engine.FORCE_TILE_ROWS = [0, 0, 4, 8][it % 4]
         tag = f"#{it} C={C} hidden={hidden} k={ks} out={out} B={B} T={T} {H}x{W} {dtype} wave={engine.FORCE_WAVE} rows={engine.FORCE_TILE_ROWS}"
         try:
+            if args.dataset:
+                from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
+                from nasa_niswan_amd.engine import LayerCfg, SeqEngine
+                from oracle import preproc_oracle as PO
+                levels = int(rng.integers(1, 5))
+                gh, gw = int(rng.integers(4, 24)), int(rng.integers(6, 48))
+                # (px >= 1: with NO longitude halo the reference's `data[..., -0:]` slice returns the whole row and the output is
+                # 2W wide -- dataset.py:67-80; `padding=None` is its way of not padding.  That accident is not reproduced.)
+                py, px = int(rng.integers(0, min(6, gh - 1))), int(rng.integers(1, min(6, gw)))
+                mode = ["reference", "reflect"][it % 2]
+                seq = int(rng.integers(1, 5))
+                Cin = 3 * levels + 2
+                tag = f"#{it} dataset levels={levels} grid={gh}x{gw} pad=({py},{px}) {mode} T={seq} {dtype}"
+                ds = SyntheticE33OMA_CRNN("train", padding=(gh + 2 * py, gw + 2 * px), in_channels=Cin, sequence_length=seq, levels=levels,
+                                          n_steps=12 + seq, grid=(gh, gw), pad_mode=mode, device="cuda", seed=it)
+                idx = [int(v) for v in rng.integers(0, len(ds), size=int(rng.integers(1, 4)))]
+                X, y = ds.device_batch(idx)
+                torch.cuda.synchronize()
+                for b, ix in enumerate(idx):
+                    (u, v, w_, pr, src), yr = ds.window(ix)
+                    sq = (lambda a: a if levels > 1 else a[:, 0])
+                    ref = PO.preproc_sample(sq(u), sq(v), sq(w_), pr, src, ds.X_mean, ds.X_std, (gh + 2 * py, gw + 2 * px), mode)
+                    np.testing.assert_allclose(X[b].cpu().numpy(), ref, rtol=1e-6, atol=1e-6, err_msg=tag)
+                # ... and straight into a model's input slab (folded or plain), then unpacked again
+                k0 = int(rng.choice([3, 5]))
+                eng = SeqEngine([LayerCfg(Cin, 16, k0)], dtype, "cuda")
+                ws = eng.acquire(len(idx), seq, gh + 2 * py, gw + 2 * px, False, False)
+                sb = ds.slab_batch(idx)[0]
+                eng.pack_input(ws, sb)
+                ws2 = eng.acquire(len(idx), seq, gh + 2 * py, gw + 2 * px, False, False)
+                eng.pack_input(ws2, X)
+                torch.cuda.synchronize()
+                assert torch.equal(ws.xs, ws2.xs), (tag, "slab path differs from preproc -> pack", bool(eng.cfgs[0].xfold))
+                print(f"ok   {tag} k0={k0} fold={bool(eng.cfgs[0].xfold)}", flush=True)
+                continue
             if args.cell:
                 Ch, k = hidden[0], ks[0]
                 has_bias = bool(it % 5)
