@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--wide", action="store_true", help="module mode with the opt-in 8-wave gate kernel forced where it is instantiated (nint_layer.wide = 2 / 3 / 4)")
     ap.add_argument("--dataset", action="store_true", help="the device preproc (z-score, level fusion, cyclic / reflect halo padding) of a resident synthetic record, as a batch tensor and through the model's input slab, against oracle/preproc_oracle.py instead")
     ap.add_argument("--cell", action="store_true", help="ConvLSTMCell(x, h, c) with a given state (forward, all five gradients) against oracle.cell_forward instead")
     ap.add_argument("--trainer", action="store_true", help="FusedTrainer.step (fused head / loss pass, flat gradient bucket) against oracle.train_step instead")
@@ -38,7 +39,11 @@ def main():
         dtype = "f32" if it % 2 == 0 else "bf16"
         engine.FORCE_WAVE = [None, 0, 1][it % 3]
         engine.FORCE_TILE_ROWS = [0, 0, 4, 8][it % 4]
-        tag = f"#{it} C={C} hidden={hidden} k={ks} out={out} B={B} T={T} {H}x{W} {dtype} wave={engine.FORCE_WAVE} rows={engine.FORCE_TILE_ROWS}"
+        if args.wide:
+            engine.FORCE_WIDE = [2, 3, 4][it % 3]
+            dtype = "bf16"
+            hidden = [int(rng.choice([64, 64, 128])) if rng.random() < 0.7 else h_ for h_ in hidden]
+        tag = f"#{it} C={C} hidden={hidden} k={ks} out={out} B={B} T={T} {H}x{W} {dtype} wave={engine.FORCE_WAVE} rows={engine.FORCE_TILE_ROWS} wide={engine.FORCE_WIDE}"
         try:
             if args.dataset:
                 from nasa_niswan_amd.dataset import SyntheticE33OMA_CRNN
@@ -169,7 +174,7 @@ def main():
             worst[dtype] = max(worst[dtype], w)
             print(f"ok   {tag}  worst {w:.2e}", flush=True)
         finally:
-            engine.FORCE_WAVE, engine.FORCE_TILE_ROWS = None, 0
+            engine.FORCE_WAVE, engine.FORCE_TILE_ROWS, engine.FORCE_WIDE = None, 0, 0
     print(f"{args.n} shapes ok; worst f32 max-rel {worst['f32']:.2e}, worst bf16 rel-L2 {worst['bf16']:.2e}")
 
 
