@@ -68,7 +68,7 @@ typedef struct nint_layer {
                            * fragments from L2: csrc/conv_igemm.hip); 1 = the same, explicitly; 2 = the persistent 8-wave kernel that
                            * stages each K-step's weight tile ONCE per workgroup in LDS (csrc/conv_wide.hip) wherever it is
                            * instantiated (bf16, gate columns a multiple of 128, k = 3 or 5, unfolded input) -- measured slower,
-                           * kept opt-in (DESIGN.md 4.5); 3 / 4 = that, with its 256- / 512-pixel tiles forced; + 8 = its taps in
+                           * kept opt-in (DESIGN.md 4.4); 3 / 4 = that, with its 256- / 512-pixel tiles forced; + 8 = its taps in
                            * plain order in every workgroup: results then equal the 4-wave kernel's bit for bit (without: every
                            * workgroup starts a chunk's taps at its own tap, i.e. another f32 summation order) */
   const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */

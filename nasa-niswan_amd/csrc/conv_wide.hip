@@ -2,7 +2,7 @@
 // weight tiles go through LDS once per workgroup (gfx950, bf16).            reference: model.py:219-229
 //
 // OPT-IN (nint_layer.wide >= 2): bit-identical to conv_igemm.hip's 4-wave kernel, a third less traffic on the texture path,
-// and 10-17 % SLOWER at the bench shape -- DESIGN.md 4.5 and profiles/r03_b_* hold the stamp / PMC record of why.  Kept
+// and 10-17 % SLOWER at the bench shape -- DESIGN.md 4.4, profiles/HISTORY.md and profiles/r03_b_* hold the stamp / PMC record of why.  Kept
 // for that record's tools (tools/wideprobe.py, tools/wide_stress.py) and tests (tests/test_gpu_wide.py).
 //
 // conv_igemm.hip's 4-wave kernel streams every wave's own weight fragments L2 -> L1 -> VGPR: for the reference's layer 0
@@ -537,7 +537,7 @@ int nint_internal_conv_wide_lstm(const ConvArgs& c, int N, int force_, void* str
   const int force = force_ & 7, rot = (force_ & 8) ? 0 : 1;
   // Measured on MI355X at the bench shape (B = 8, 100 x 154, 62 + 64 -> 256, k = 5): 187-200 us per launch in the step against
   // 167-171 us for the 4-wave kernel -- the K loop runs ~1950 cycles per K-step instead of the ~1000 it reaches with the DMA
-  // issue ablated (an LDS-DMA piece costs its issuing wave ~200 cycles, a halo gather piece far more, and the
+  // issue ablated (profiles/HISTORY.md: an LDS-DMA piece costs its issuing wave ~200 cycles, a halo gather piece far more, and the
   // barrier-coupled loop makes all eight waves wait for it).
   if (!force) return NINT_E_SHAPE;
   if (c.kx0 != c.k || (c.k != 3 && c.k != 5) || c.nchunk0 + c.nchunk1 < 1) return NINT_E_SHAPE;

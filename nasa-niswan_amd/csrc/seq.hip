@@ -91,7 +91,7 @@ extern "C" int nint_selftest(float* out, void* stream) {
 // ------------------------------------------------------------------------------ sequence drivers
 // Every launch of a pass is enqueued from C++ on the CALLER's stream, in dependency order.  The library owns no
 // streams, events or other state.  At the bench's batch size a (t, layer) wavefront on side streams and weight-gradient
-// reductions overlapped with the BPTT chain were both at or below this order (DESIGN.md 4.3: co-resident
+// reductions overlapped with the BPTT chain were both at or below this order (DESIGN.md 4.4: co-resident
 // MFMA-bound kernels evict each other's LDS / register budget; every cross-stream edge is a marker on the first layer's
 // chain).  For small batches the forward wavefront runs as ONE grid per step instead (nint_seq.wave, conv_lstm_multi_kernel).
 static inline size_t esize(int dtype) { return dtype == NINT_BF16 ? 2 : 4; }
@@ -199,7 +199,7 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
 }
 
 // default of the "lower layer's pointwise backward on the fused layer's x columns" option: on (measured inside the bench
-// step, five alternations on one device: 962.2 -> 963.6 samples/s, every pair positive)
+// step, five alternations on one device: 962.2 -> 963.6 samples/s, every pair positive; profiles/HISTORY.md)
 #ifndef NINT_AUTO_LO
 #define NINT_AUTO_LO true
 #endif

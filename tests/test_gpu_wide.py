@@ -104,7 +104,7 @@ def test_forced_kernel_family_trains_the_bench_workload_like_the_oracle(pkg, wid
 
 
 def test_every_family_code_runs_every_batch(pkg):
-    """nint_layer.wide = 0 (the library's choice: the 4-wave kernel, which measured faster -- DESIGN.md 4.5), 2 (the wide
+    """nint_layer.wide = 0 (the library's choice: the 4-wave kernel, which measured faster -- DESIGN.md 4.4), 2 (the wide
     kernel wherever instantiated), 3 / 4 (its tile size forced), all with the plain tap order (+ 8): bit-identical results
     at B = 1 (63 tiles: most CUs idle), 2 and 8 (two units per persistent workgroup)."""
     for B in (1, 2, 8):
