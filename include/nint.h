@@ -114,11 +114,15 @@ typedef struct nint_seq {
                                         * fills slots from 0, nint_seq_bwd from probe_slots / 2; each starts with two back-to-back
                                         * calibration stamps (kind 0).  tag = kind | layer << 8 | t << 16 | end << 31 */
   int32_t probe_slots;
-  /* (t, layer) wavefront of the FORWARD pass (model.py:265-271: gate(l, t) needs gate(l-1, t) and gate(l, t-1) only, so
-   * gate(0, t+1), gate(1, t), gate(2, t-1) are independent).  wave != 0: each wavefront step is enqueued as ONE grid holding
-   * the workgroups of all its gate launches (T + L - 1 launches instead of T * L) -- for the strong-scaling shape (B = 1-2
-   * per GPU), where one layer's launch does not fill 256 CUs.  Same workgroups on the same data: bit-identical results.
-   * Falls back to one launch per (layer, step) for shapes the merged grid does not hold (8-row tiles, the 8-wave kernel). */
+  /* Independent launches as ONE grid, for the strong-scaling shapes (B <= ~5 per GPU at 100 x 154), where one layer's launch
+   * does not fill 256 CUs.  wave != 0:
+   *   nint_seq_fwd runs the (t, layer) wavefront (model.py:265-271: gate(l, t) needs gate(l-1, t) and gate(l, t-1) only, so
+   *     gate(0, t+1), gate(1, t), gate(2, t-1) are independent): each wavefront step is one grid holding the workgroups of
+   *     all its gate launches (T + L - 1 launches instead of T * L);
+   *   nint_seq_bwd enqueues the bottom layer's dgrad of one BPTT step together with the top layer's fused step of the next
+   *     (adjacent launches that share no buffer in a stack of three or more layers).
+   * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
+   * not hold (the register-heavy fused shapes, the 8-wave kernel, more than 4 layers).  Ignored while probes are on. */
   int32_t wave;
 } nint_seq;
 
