@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", action="store_true", help="module mode on grids around the bench size (60-110 x 100-170, ragged), B = 1-3, T = 1-3")
     ap.add_argument("--wide", action="store_true", help="module mode with the opt-in 8-wave gate kernel forced where it is instantiated (nint_layer.wide = 2 / 3 / 4)")
     ap.add_argument("--dataset", action="store_true", help="the device preproc (z-score, level fusion, cyclic / reflect halo padding) of a resident synthetic record, as a batch tensor and through the model's input slab, against oracle/preproc_oracle.py instead")
     ap.add_argument("--cell", action="store_true", help="ConvLSTMCell(x, h, c) with a given state (forward, all five gradients) against oracle.cell_forward instead")
@@ -36,6 +37,8 @@ def main():
         out = int(rng.choice([1, 2, 5, 20, 20, 200]))
         B, T = int(rng.integers(1, 6)), int(rng.integers(1, 5))
         H, W = int(rng.integers(5, 40)), int(rng.integers(9, 70))
+        if args.big:
+            H, W, B, T = int(rng.integers(60, 111)), int(rng.integers(100, 171)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
         dtype = "f32" if it % 2 == 0 else "bf16"
         engine.FORCE_WAVE = [None, 0, 1][it % 3]
         engine.FORCE_TILE_ROWS = [0, 0, 4, 8][it % 4]
