@@ -217,6 +217,34 @@ def probe_durations(words_fwd, words_bwd):
     return res
 
 
+def probe_steps(trainer, X, y, rank, pbuf, mask, psteps, slots, timer=None):
+    """The in-step pricing pass: `psteps` + 1 more trainer.step() calls ON EVERY RANK -- under a process group every step
+    ends in the gradient all-reduce, so a pass that only rank 0 ran would leave its collectives without a peer (an RCCL
+    hang; the round-3 advisor's finding).  Only rank 0 attaches the probe buffer and parses it; the other ranks run the
+    same steps without stamps.  `timer`: callable returning (record_start, record_stop_and_ms) -- HIP events on the GPU,
+    wall clock in the CPU test.  Returns (durations, step_ms) on rank 0, (None, None) elsewhere."""
+    import torch
+    probing = rank == 0 and pbuf is not None
+    if probing:
+        trainer.set_probe(pbuf, mask)
+    dur, step_ms = {}, []
+    for _ in range(psteps):
+        if probing:
+            pbuf.zero_()
+            start, stop_ms = timer() if timer else (lambda: None, lambda: 0.0)
+            start()
+        trainer.step(X, y)
+        if probing:
+            step_ms.append(stop_ms())
+            w = pbuf.cpu().numpy()
+            for key, v in probe_durations(w[:slots], w[slots:]).items():
+                dur.setdefault(key, []).extend(v)
+    if probing:
+        trainer.set_probe(None)
+    trainer.step(X, y)                      # one step without probes: workspaces leave the pass as the timed steps left them
+    return (dur, step_ms) if probing else (None, None)
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -275,6 +303,7 @@ def main():
             loss_ = trainer.step(X, y)
         sync()
         el = time.perf_counter() - t0
+        timed.local = el
         if use_dist:
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -284,6 +313,7 @@ def main():
     for _ in range(args.warmup):
         trainer.step(X, y)
     elapsed, loss = timed(args.steps)
+    local_elapsed = timed.local
     final_loss = float(loss)
     long_elapsed = timed(args.long_steps)[0] if args.long_steps > 0 else None
 
@@ -310,36 +340,45 @@ def main():
         # ring all-reduce: every rank sends and receives 2 (N-1)/N of the bucket; "bus bandwidth" as nccl-tests define it
         bus_bw = (2.0 * (world - 1) / world) * nbytes / (ar_ms * 1e-3) / 1e9 if world > 1 else None
 
+    # ---- per-rank step time (N > 1): the slowest rank sets `value`; the spread says whether one device lags
+    rank_ms = None
+    if use_dist:
+        mine = torch.tensor([1e3 * local_elapsed / args.steps], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [round(float(t), 3) for t in allr]
+
     # ---- kernel rooflines, priced in the step (probe pass) and in a warm loop (HIP events)
     roof, roof_all, phases = None, None, None
-    if rank == 0 and not args.no_kernel_rooflines:
+    eng = model._engine(dev)
+    wave_on = None
+    for wsl in eng.pool.values():
+        for ws_ in wsl:
+            wave_on = bool(ws_.seq.wave)            # the launch schedule of the timed steps (nint_seq.wave)
+    PSTEPS, SLOTS = 5, 2048
+    dur = step_ms = None
+    if not args.no_kernel_rooflines:
+        # probe pass: PSTEPS more steps with stamps around the layer-0 gate / dgrad / pointwise launches, every layer's
+        # weight-gradient block and the fold.  EVERY rank runs the steps (each ends in the all-reduce); rank 0 alone stamps.
+        pbuf = torch.zeros(2 * SLOTS, dtype=torch.int64, device=dev) if rank == 0 else None
+        mask = (1 << PROBE_GATE) | (1 << PROBE_POINTWISE) | (1 << PROBE_DGRAD) | (1 << PROBE_FUSED) | (1 << PROBE_WGRAD) | (1 << PROBE_FOLD)
+        st_ = torch.cuda.current_stream()
+
+        def ev_timer():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def stop():
+                e1.record(st_)
+                e1.synchronize()
+                return e0.elapsed_time(e1)
+            return (lambda: e0.record(st_)), stop
+        dur, step_ms = probe_steps(trainer, X, y, rank, pbuf, mask, PSTEPS, SLOTS, ev_timer)
+    if rank == 0 and dur is not None:
         import ctypes as Ct
         import numpy as np
-        eng = model._engine(dev)
         lib = pkg.load_library()
         st = torch.cuda.current_stream()
         k0, ch0 = ks[0], hidden[0]
-        # probe pass: PSTEPS more steps with stamps around the layer-0 gate / dgrad / pointwise launches, every layer's
-        # weight-gradient block and the fold; forward and backward phases bracketed with HIP events
-        PSTEPS, SLOTS = 5, 2048
-        pbuf = torch.zeros(2 * SLOTS, dtype=torch.int64, device=dev)
-        mask = (1 << PROBE_GATE) | (1 << PROBE_POINTWISE) | (1 << PROBE_DGRAD) | (1 << PROBE_FUSED) | (1 << PROBE_WGRAD) | (1 << PROBE_FOLD)
-        trainer.set_probe(pbuf, mask)
-        dur = {}
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        step_ms = []
-        for _ in range(PSTEPS):
-            pbuf.zero_()
-            ev[0].record(st)
-            trainer.step(X, y)
-            ev[1].record(st)
-            ev[1].synchronize()
-            step_ms.append(ev[0].elapsed_time(ev[1]))
-            w = pbuf.cpu().numpy()
-            for key, v in probe_durations(w[:SLOTS], w[SLOTS:]).items():
-                dur.setdefault(key, []).extend(v)
-        trainer.set_probe(None)
-        trainer.step(X, y)
 
         def mean_us(kind, layer, pred=lambda t: True):
             v = [us for t, us in dur.get((kind, layer), []) if pred(t)]
@@ -373,7 +412,8 @@ def main():
             tr = traffic.get(f"{args.workload}/{args.dtype}/B{B}/{key}", {}).get("bytes_per_launch")
             e = {"kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": pk, "unit": unit,
                  "frac": round(ach / pk, 4), "traffic": tr, "ms_per_launch": round(use, 4),
-                 "timing": "in-step (nint_seq.probe stamps)" if ms is not None else "warm loop (HIP events)",
+                 "timing": ("in-step (nint_seq.probe stamps" + ("; time-major launches, the timed steps ran merged grids)" if wave_on else ")"))
+                           if ms is not None else "warm loop (HIP events)",
                  "ms_per_launch_loop": round(ms_loop, 4), "frac_loop": round(ach / pk * use / ms_loop, 4),
                  ("flops_per_launch" if bound == "mfma" else "bytes_per_launch"): work}
             if note:
@@ -434,7 +474,12 @@ def main():
         names = {PROBE_GATE: "gate", PROBE_POINTWISE: "pointwise", PROBE_DGRAD: "dgrad", PROBE_FUSED: "fused_bptt_step",
                  PROBE_WGRAD: "wgrad", PROBE_FOLD: "fold"}
         phases = {"step_ms_with_probes": round(float(np.median(step_ms)), 3),
-                  "probe_pair_cost_us": round(float(np.mean(dur.get("cal_us", [0.0]))), 2), "per_step_us": {}}
+                  "probe_pair_cost_us": round(float(np.mean(dur.get("cal_us", [0.0]))), 2),
+                  # the probes bracket single launches, so the library runs the time-major order while they are on; when the
+                  # timed steps ran merged grids (config.wave: small batches) the figures below price the launches of the
+                  # time-major schedule, not the merged ones
+                  "wave": False, "schedule_differs_from_timed_steps": bool(wave_on),
+                  "per_step_us": {}}
         for key, v in sorted((k, v) for k, v in dur.items() if k != "cal_us"):
             phases["per_step_us"][f"{names[key[0]]}{key[1]}"] = {"launches": len(v) // PSTEPS,
                                                                   "us_per_step": round(sum(us for _, us in v) / PSTEPS, 1),
@@ -452,7 +497,10 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": args.workload, "in_channels": C, "hidden": list(hidden), "kernels": list(ks),
                        "out_channels": out, "seq_len": T, "padded_grid": [Hp, Wp], "grid": list(grid),
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "wave": wave_on},
+            # which build produced the line: the product library next to the package, or an A/B copy (--lib)
+            "lib": os.path.realpath(args.lib) if args.lib else "product", "nint_version": int(pkg.load_library().nint_version()),
             # the same measurement over a window long enough that the timer does not matter (the headline window is 0.17 s)
             "value_200steps": None if long_elapsed is None else round(world * B * args.long_steps / long_elapsed, 3),
             "long_window": None if long_elapsed is None else {"steps": args.long_steps, "seconds": round(long_elapsed, 3)},
@@ -466,7 +514,10 @@ def main():
             "whole_step_tflops": round(value * f_train / 1e12, 2),
             "whole_step_mfma_frac": round(value * f_train / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4),
             "final_loss": round(final_loss, 5),
+            # N > 1: every rank's own step time (the headline uses the slowest), and the exchange step's share of the step
+            "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
+            "allreduce_frac_of_step": None if ar_ms is None else round(ar_ms / (1e3 * elapsed / args.steps), 4),
             "allreduce_bytes": trainer.flat.grad.numel() * 4 if use_dist else None,
             "bus_bw_GBs": None if bus_bw is None else round(bus_bw, 2),
             "bus_bw_bound_GBs": XGMI_LINK_GBS if world > 1 else None,

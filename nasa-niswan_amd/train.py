@@ -48,7 +48,7 @@ def get_arguments(argv=None, MODEL='LSTM-00', SPECIES='bcb', LEARNING_RATE=1.0E-
     parser.add_argument("--kernel-size", nargs='+', type=int, default=KERNEL_SIZE)
     parser.add_argument("--num-layers", type=int, default=NUM_LAYERS)
     parser.add_argument("--sequence-length", type=int, default=SEQUENCE_LENGTH)
-    parser.add_argument("--transform", action="store_true", default=TRANSFORM)
+    parser.add_argument("--transform", action="store_true", default=TRANSFORM)     # parsed, never read here: the reference passes it to the UNet datasets only (train.py:52-57), its CRNN datasets take no transform (train.py:59-64)
     parser.add_argument("--num-epochs", type=int, default=NUM_EPOCHS)
     parser.add_argument("--input-size", nargs=2, type=int, default=INPUT_SIZE)
     parser.add_argument("--batch-size", type=int, default=BATCH_SIZE)

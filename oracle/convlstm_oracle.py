@@ -58,12 +58,19 @@ def num_layers_of(params: Dict[str, torch.Tensor]) -> int:
 
 
 # --------------------------------------------------------------------------- cell
-def cell_forward(x, h, c, weight, bias):
-    """reference model.py:216-231.  x (B,Cin,H,W); h,c (B,Ch,H,W)."""
+def cell_forward(x, h, c, weight, bias, preact: Optional[list] = None):
+    """reference model.py:216-231.  x (B,Cin,H,W); h,c (B,Ch,H,W).
+    ``preact``: a list that receives the pre-activation gate tensor (B,4Ch,H,W), out-channel order [i,f,g,o], with
+    ``retain_grad()`` set -- after ``backward()`` its ``.grad`` is the dG of SURVEY.md section 8 a-5, which the tests
+    compare with the dG slab the BPTT kernels store."""
     ch = h.shape[1]
     k = weight.shape[-1]
     combined = torch.cat([x, h], dim=1)                          # model.py:219
     gates = F.conv2d(combined, weight, bias, padding=k // 2)     # model.py:220 (zeros padding)
+    if preact is not None:
+        if gates.requires_grad:
+            gates.retain_grad()
+        preact.append(gates)
     gi, gf, gg, go = torch.split(gates, ch, dim=1)               # model.py:221
     gi = torch.sigmoid(gi)                                       # model.py:223
     gf = torch.sigmoid(gf)                                       # model.py:224
@@ -115,12 +122,14 @@ def head_forward(h, w_head, b_head):
 
 
 def convlstm_forward(x, params, return_states: bool = False, return_sequence: bool = False,
-                     h0: Optional[List[torch.Tensor]] = None, c0: Optional[List[torch.Tensor]] = None):
+                     h0: Optional[List[torch.Tensor]] = None, c0: Optional[List[torch.Tensor]] = None,
+                     preact: Optional[Dict[Tuple[int, int], torch.Tensor]] = None):
     """reference model.py:253-274.  x (B,T,C,H,W) -> (B,out,H,W).
 
     ``return_sequence`` restates the commented-out variant (model.py:264,272,274) that
     the analysis notebook was run with (test.ipynb:273): per-step head outputs
-    concatenated on the channel axis."""
+    concatenated on the channel axis.  ``preact``: a dict that receives {(layer, t): pre-activation gates}
+    (see :func:`cell_forward`)."""
     L = num_layers_of(params)
     B, T, _, H, W = x.shape
     hs, cs = [], []
@@ -132,8 +141,11 @@ def convlstm_forward(x, params, return_states: bool = False, return_sequence: bo
     for t in range(T):                                           # model.py:265
         x_t = x[:, t]                                            # model.py:266
         for i in range(L):                                       # model.py:267
+            pa = [] if preact is not None else None
             h, c = cell_forward(x_t, hs[i], cs[i], params[f"layers.{i}.conv.weight"],
-                                params[f"layers.{i}.conv.bias"])  # model.py:269
+                                params[f"layers.{i}.conv.bias"], pa)  # model.py:269
+            if pa:
+                preact[(i, t)] = pa[0]
             hs[i], cs[i] = h, c                                  # model.py:270
             x_t = h                                              # model.py:271
         if return_sequence:

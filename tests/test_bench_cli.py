@@ -46,12 +46,12 @@ def test_gpus_n_builds_the_torchrun_child_command(monkeypatch):
 def test_gpus_2_really_starts_two_ranks_and_returns_their_failure_here():
     """No GPU in this container: both ranks must get as far as the device check and refuse (there is no CPU path), and the
     parent must hand their failure back as its own exit code -- after having decided to spawn from argv alone."""
+    import torch
+    if torch.cuda.is_available():             # (decided BEFORE anything is started: on a GPU box the two ranks would go for the card)
+        pytest.skip("meant for the CPU-only container")
     env = dict(os.environ, MASTER_PORT="29611")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--master-port", "29611"], capture_output=True, text=True, env=env, timeout=280)
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("meant for the CPU-only container")
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
 
@@ -79,3 +79,51 @@ def test_strong_scaling_divides_the_global_batch():
     a = bench.parse_args(["--gpus", "8", "--scaling", "strong"])
     assert a.batch == 8 and a.scaling == "strong"             # 8 in all -> 1 per GPU (main() divides by the world size)
     assert bench.parse_args([]).scaling == "weak" and bench.parse_args([]).long_steps == 200
+
+
+# ------------------------------------------------------------------------------------------ the probe pass under a process group
+def _probe_worker(rank, world, port, out):
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=30))
+    bench = _bench()
+
+    class StubTrainer:                        # what FusedTrainer.step does under a process group: ONE all-reduce per step
+        def __init__(self):
+            self.steps, self.bucket, self.probed = 0, torch.ones(1000), 0
+
+        def set_probe(self, buf, mask=0):
+            self.probed += buf is not None
+
+        def step(self, X, y):
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+            self.bucket.mul_(1.0 / world)
+            self.steps += 1
+
+    tr = StubTrainer()
+    pbuf = torch.zeros(2 * 64, dtype=torch.int64) if rank == 0 else None
+    dur, step_ms = bench.probe_steps(tr, None, None, rank, pbuf, 0x7E, 3, 64)
+    t = torch.tensor([float(tr.steps)])
+    dist.all_reduce(t)                        # pairs up only if both ranks left the pass with the same number of collectives
+    dist.barrier()
+    torch.save({"steps": tr.steps, "sum": float(t), "probed": tr.probed, "dur": dur is not None}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_probe_pass_keeps_collectives_symmetric_across_ranks(tmp_path):
+    """bench.py's in-step pricing pass runs extra trainer.step() calls, each ending in the gradient all-reduce: every rank
+    must run them (rank 0 alone stamps), or rank 0's collectives have no peer and `--gpus N` never prints its line
+    (round-3 advisor finding).  Two gloo ranks, a stub step that is just the all-reduce: with a rank-0-only pass this
+    test dies in the 30 s collective timeout."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "probe")
+    mp.spawn(_probe_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["steps"] == r1["steps"] == 4 and r0["sum"] == 8.0          # 3 probed steps + 1 plain one, on both ranks
+    assert r0["dur"] and not r1["dur"] and r0["probed"] == 1 and r1["probed"] == 0

@@ -16,6 +16,36 @@ from nasa_niswan_amd import engine  # noqa: E402
 from oracle import convlstm_oracle as O  # noqa: E402
 
 
+def stored_dG(eng, ws, l):
+    """ws.dG[l] (ET halo slab [T*B][Hh][Wh][4*Ch16], column (cblock*4+gate)*16+col) -> f32 (T*B, 4*Ch, H, W) in the reference's
+    out-channel order [i,f,g,o]: the summands the weight-gradient kernel reduced (layout only, no arithmetic)."""
+    g, cfg = ws.g, eng.cfgs[l]
+    Ch16 = (cfg.Ch + 15) // 16 * 16
+    N = ws.T * ws.B
+    t = ws.dG[l].view(torch.bfloat16 if eng.es == 2 else torch.float32).view(N, g.Hh, g.Wh, 4 * Ch16)
+    t = t[:, g.P:g.P + ws.H, g.P:g.P + ws.W, :].float()
+    t = t.reshape(N, ws.H, ws.W, Ch16 // 16, 4, 16).permute(0, 4, 3, 5, 1, 2).reshape(N, 4, Ch16, ws.H, ws.W)
+    return t[:, :, :cfg.Ch].reshape(N, 4 * cfg.Ch, ws.H, ws.W)
+
+
+def check_bias_grad(tag, name, db, dbo, dG_stored, dG_oracle, dtype):
+    """The bias gradient is a sum that cancels (tests/test_gpu_bias_grad.py): bf16 mode is gated on its two factors instead of
+    on a loose end-to-end figure -- (1) db equals the f32 column sum of the dG slab the kernels STORED (1e-5 of its max:
+    a dropped or doubled tile shows here whatever the cancellation), (2) what separates it from the oracle is a sum of
+    per-pixel errors of dG (the elementwise gate is 3e-2 rel-L2) that do not add coherently: |err| <= 3e-2 * ||dG_col||_2
+    + 3e-2 * |db|.  Returns the plain rel-L2 against the oracle for the log (worst seen: 7.7e-2, a B = 1, T = 1 top layer)."""
+    db, dbo = db.double(), dbo.double()
+    if dG_stored is not None:
+        colsum = dG_stored.double().sum(dim=(0, 2, 3))
+        e1 = float((db - colsum).abs().max() / (colsum.abs().max() + 1e-30))
+        assert e1 <= 1e-5, (tag, name, "bias gradient is not the column sum of the stored dG slab", e1)
+    l2col = dG_oracle.double().pow(2).sum(dim=(0, 2, 3)).sqrt()
+    bound = 3e-2 * l2col + 3e-2 * dbo.abs() + 1e-30
+    worst = float(((db - dbo).abs() / bound).max())
+    assert worst <= 1.0, (tag, name, "bias gradient outside the cancellation bound", worst)
+    return float((db - dbo).norm() / (dbo.norm() + 1e-30))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
@@ -104,7 +134,8 @@ def main():
                 xo, ho, co = (t.clone().requires_grad_(True) for t in (x, h, c))
                 Wo = Wt.clone().requires_grad_(True)
                 bo = bt.clone().requires_grad_(True) if has_bias else None
-                h1o, c1o = O.cell_forward(xo, ho, co, Wo, bo)
+                pre = []
+                h1o, c1o = O.cell_forward(xo, ho, co, Wo, bo, pre)
                 ((h1o * gh).sum() + (c1o * gc).sum()).backward()
                 res = {"h1": (h1.detach().cpu(), h1o.detach()), "c1": (c1.detach().cpu(), c1o.detach()), "dx": (xd.grad.cpu(), xo.grad),
                        "dh": (hd.grad.cpu(), ho.grad), "dc": (cd.grad.cpu(), co.grad), "dW": (cell.conv.weight.grad.cpu(), Wo.grad)}
@@ -114,8 +145,13 @@ def main():
                 for k2, (a, b) in res.items():
                     a, b = a.double(), b.double()
                     assert torch.isfinite(a).all(), (tag, k2)
+                    if dtype == "bf16" and k2.endswith("bias"):
+                        eng = cell._engine(xd.device)
+                        (ws,) = eng.pool[(B, 1, H, W, True, True)]
+                        check_bias_grad(tag, k2, a, b, stored_dG(eng, ws, 0).cpu(), pre[0].grad, dtype)
+                        continue
                     e = float((a - b).abs().max() / (b.abs().max() + 1e-30)) if dtype == "f32" else float((a - b).norm() / (b.norm() + 1e-30))
-                    assert e <= (1e-3 if dtype == "f32" else (0.15 if k2.endswith("bias") else 3e-2)), (tag, k2, e)
+                    assert e <= (1e-3 if dtype == "f32" else 3e-2), (tag, k2, e)
                     w = max(w, e)
                 worst[dtype] = max(worst[dtype], w)
                 print(f"ok   {tag}  worst {w:.2e}", flush=True)
@@ -156,7 +192,8 @@ def main():
             torch.cuda.synchronize()
             leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
             Xo = X.clone().requires_grad_(True)
-            po = O.convlstm_forward(Xo, leaf)
+            pre = {}
+            po = O.convlstm_forward(Xo, leaf, preact=pre)
             (po * wgt).sum().backward()
             res = {"pred": (pred.detach().cpu(), po.detach()), "dX": (Xd.grad.cpu(), Xo.grad)}
             for k, p in net.named_parameters():
@@ -168,11 +205,16 @@ def main():
                 if dtype == "f32":
                     e = float((a - b).abs().max() / (b.abs().max() + 1e-30))
                     assert e <= 1e-3, (tag, k, e)
+                elif k.startswith("grad.layers.") and k.endswith("bias"):
+                    # sums that cancel: gated on their two factors, not on the end-to-end figure (check_bias_grad)
+                    l = int(k.split(".")[2])
+                    eng = net._engine(Xd.device)
+                    (ws,) = eng.pool[(B, T, H, W, True, False)]
+                    check_bias_grad(tag, k, a, b, stored_dG(eng, ws, l).cpu(), torch.cat([pre[(l, t)].grad for t in range(T)]), dtype)
+                    continue
                 else:
                     e = float((a - b).norm() / (b.norm() + 1e-30))
-                    # (bias gradients are sums with heavy cancellation over bf16-rounded gate gradients -- 4-8 % seen for the top
-                    # layer of B = 1, T = 1 cases; the same shapes are exact to 1e-6 in f32 mode, which half of the cases run)
-                    assert e <= (0.15 if k.endswith("bias") else 3e-2), (tag, k, e)
+                    assert e <= 3e-2, (tag, k, e)
                 w = max(w, e)
             worst[dtype] = max(worst[dtype], w)
             print(f"ok   {tag}  worst {w:.2e}", flush=True)
