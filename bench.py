@@ -159,7 +159,7 @@ def parse_args(argv=None):
     ap.add_argument("--long-steps", type=int, default=200, help="steps of the extra long window (value_200steps); 0 = skip")
     ap.add_argument("--fuse-bwd", type=lambda v: int(v, 0), default=0,
                     help="nint_seq.fuse_bwd (BPTT schedule; 0 = the library's per-layer choice, 0x40000000|masks = explicit, see nint.h)")
-    ap.add_argument("--wide", type=int, default=0, help="nint_layer.wide of every layer (0 = the library's choice, 1 = 4-wave kernels, 2 = 8-wave LDS-weight kernel)")
+    ap.add_argument("--wide", type=int, default=0, help="nint_layer.wide of every layer: weight-gradient kernel family (0 = the library's choice, 1 = 4-wave 64-column kernel, 2 = 8-wave 128-column kernel where instantiated)")
     ap.add_argument("--wave", type=int, default=-1, choices=[-1, 0, 1],
                     help="forward (t, layer) wavefront, one grid per step (nint_seq.wave): -1 = the engine's rule (small batches), 0 = off, 1 = on")
     ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape)")

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 108
+#define NINT_VERSION 109
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
 
@@ -64,13 +64,13 @@ typedef struct nint_layer {
                            * kx*Cx + c holds x[.., x + kx - k/2][c] (0 outside the image), Cxp = roundup(k*Cx, KC), and
                            * the x part of K is k vertical taps x k*Cx channels instead of k*k taps x Cx channels padded
                            * to KC each (reference layer 0: Conv2d(5+64 -> 256, k=5), model.py:207-211: 5 x-steps, not 25) */
-  int32_t wide;           /* gate kernel family: 0 = the library's choice (the 4-wave kernels, whose waves stream their own weight
-                           * fragments from L2: csrc/conv_igemm.hip); 1 = the same, explicitly; 2 = the persistent 8-wave kernel that
-                           * stages each K-step's weight tile ONCE per workgroup in LDS (csrc/conv_wide.hip) wherever it is
-                           * instantiated (bf16, gate columns a multiple of 128, k = 3 or 5, unfolded input) -- measured slower,
-                           * kept opt-in; 3 / 4 = that, with its 256- / 512-pixel tiles forced; + 8 = its taps in
-                           * plain order in every workgroup: results then equal the 4-wave kernel's bit for bit (without: every
-                           * workgroup starts a chunk's taps at its own tap, i.e. another f32 summation order) */
+  int32_t wide;           /* weight-gradient kernel family (csrc/wgrad.hip): 0 = the library's choice (the 8-wave kernel with a
+                           * 128-gate-column output block wherever it is instantiated and the layer is wide enough, else
+                           * the 4-wave 64-column kernel); 1 = always the 4-wave kernel; 2 = the 8-wave kernel wherever it is
+                           * instantiated (bf16, k = 3 / 5 / 7, unfolded sources, gate columns a multiple of 128, channel
+                           * counts a multiple of its channel group), whatever the layer's width.  Same sums in another f32
+                           * order.  (Rounds 2-3 used this field for an 8-wave GATE kernel that measured slower everywhere
+                           * and left the library in round 4: tools/experiments/.) */
   const void* Wf;         /* fwd weights, MFMA-fragment order, ET   (nint_pack_weights) */
   const void* Wd;         /* dgrad weights (transposed + flipped), ET */
   const float* bias_p;    /* bias permuted to gate-stash column order [4*Ch16] */
@@ -122,7 +122,7 @@ typedef struct nint_seq {
    *   nint_seq_bwd enqueues the bottom layer's dgrad of one BPTT step together with the top layer's fused step of the next
    *     (adjacent launches that share no buffer in a stack of three or more layers).
    * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
-   * not hold (the register-heavy fused shapes, the 8-wave kernel, more than 4 layers).  Ignored while probes are on. */
+   * not hold (the register-heavy fused shapes, more than 4 layers).  Ignored while probes are on. */
   int32_t wave;
 } nint_seq;
 

@@ -479,7 +479,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, c
           gf[r] = sigmoidf_(acc[i][cb * 4 + 1][r]);
           gg[r] = tanhf_(acc[i][cb * 4 + 2][r]);
           go[r] = sigmoidf_(acc[i][cb * 4 + 3][r]);
-          cn[r] = fmaf(cp[r], gf[r], gi[r] * gg[r]);   // model.py:228 (the association is pinned: the 4-wave, merged-grid and 8-wave kernels agree bit for bit)
+          cn[r] = fmaf(cp[r], gf[r], gi[r] * gg[r]);   // model.py:228 (the association is pinned: every kernel family agrees bit for bit)
           hn[r] = go[r] * tanhf_(cn[r]);               // model.py:229
         }
         if (ok) {
@@ -891,12 +891,7 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
   a.tile_rows = ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
-  if (ly->wide < 0 || ly->wide > 12 || (ly->wide & 7) > 4) return NINT_E_ARG;
-  if (plan && (ly->wide & 7) > 1) return NINT_E_SHAPE;  // (the 8-wave kernel is a launch of its own)
-  if (!plan && dtype == NINT_BF16 && (ly->wide & 7) != 1) {     // wide layers with enough tiles: the 8-wave LDS-weight kernel (conv_wide.hip)
-    const int rc = nint_internal_conv_wide_lstm(a, N, ly->wide, stream);
-    if (rc != NINT_E_SHAPE) return rc;
-  }
+  if (ly->wide < 0 || ly->wide > 2) return NINT_E_ARG;   // (the weight-gradient family switch: nothing to do with this launch)
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st, plan)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st, plan);
 }

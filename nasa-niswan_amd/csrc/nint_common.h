@@ -175,9 +175,6 @@ struct WgJob {           // one layer's weight / bias gradient
 };
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
                                    size_t partial_bytes, int n_cu, void* stream, Probe* probe = nullptr);
-// conv_wide.hip: the persistent 8-wave gate kernel with the weight tiles staged once per workgroup in LDS (bf16, wide layers).
-// force = nint_layer.wide == 2.  NINT_E_SHAPE = not served: the caller takes conv_igemm.hip's 4-wave kernel.
-int nint_internal_conv_wide_lstm(const ConvArgs& a, int N, int force, void* stream);
 #define NINT_MULTI_MAX 4  // problems per merged grid (conv_lstm_multi_kernel / conv_bwd_multi_kernel)
 struct CellFwdJob {      // one gate launch (nint_cell_fwd's arguments)
   const nint_layer* ly; const void* x_slab; const void* h_prev; const float* c_prev; void* h_out; float* c_out; void* gates_out;

@@ -20,8 +20,8 @@ FORCE_TILE_ROWS = 0
 # packs: row tiles up to 160 KiB go through the LDS-tiled pack kernel, wider ones through the per-element one.)  False keeps the plain
 # channel-padded layout for engines built afterwards (tests run both).
 XFOLD = True
-# nint_layer.wide of engines built afterwards: 0 = the library picks the gate / dgrad kernel family per launch shape, 1 = always
-# the 4-wave kernels (csrc/conv_igemm.hip), 2 = the 8-wave LDS-weight kernel (csrc/conv_wide.hip) wherever it is instantiated
+# nint_layer.wide of engines built afterwards (weight-gradient kernel family): 0 = the library's choice, 1 = always the 4-wave
+# 64-column kernel, 2 = the 8-wave 128-column kernel wherever it is instantiated (tests run both against each other)
 FORCE_WIDE = 0
 FORCE_WAVE = None        # forward (t, layer) wavefront as one grid per step: None = by batch size (SeqEngine._set_wave), 0 = never, 1 = always
 WAVE_TILES_PER_CU = 5     # ... on while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs

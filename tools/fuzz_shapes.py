@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--n", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--big", action="store_true", help="module mode on grids around the bench size (60-110 x 100-170, ragged), B = 1-3, T = 1-3")
-    ap.add_argument("--wide", action="store_true", help="module mode with the opt-in 8-wave gate kernel forced where it is instantiated (nint_layer.wide = 2 / 3 / 4)")
+    ap.add_argument("--wide", action="store_true", help="module mode on shapes the 8-wave 128-column weight-gradient kernel holds (bf16, hidden 32 / 64 / 128), the family forced on and off (nint_layer.wide = 2 / 1)")
     ap.add_argument("--dataset", action="store_true", help="the device preproc (z-score, level fusion, cyclic / reflect halo padding) of a resident synthetic record, as a batch tensor and through the model's input slab, against oracle/preproc_oracle.py instead")
     ap.add_argument("--cell", action="store_true", help="ConvLSTMCell(x, h, c) with a given state (forward, all five gradients) against oracle.cell_forward instead")
     ap.add_argument("--trainer", action="store_true", help="FusedTrainer.step (fused head / loss pass, flat gradient bucket) against oracle.train_step instead")
@@ -73,9 +73,11 @@ def main():
         engine.FORCE_WAVE = [None, 0, 1][it % 3]
         engine.FORCE_TILE_ROWS = [0, 0, 4, 8][it % 4]
         if args.wide:
-            engine.FORCE_WIDE = [2, 3, 4][it % 3]
+            engine.FORCE_WIDE = [2, 2, 1][it % 3]
             dtype = "bf16"
-            hidden = [int(rng.choice([64, 64, 128])) if rng.random() < 0.7 else h_ for h_ in hidden]
+            hidden = [int(rng.choice([32, 64, 64, 128])) if rng.random() < 0.8 else h_ for h_ in hidden]
+            ks = [int(rng.choice([3, 3, 5, 7])) if k_ == 1 else k_ for k_ in ks]
+            C = int(rng.choice([32, 62, 64, 126, 128])) if rng.random() < 0.7 else C
         tag = f"#{it} C={C} hidden={hidden} k={ks} out={out} B={B} T={T} {H}x{W} {dtype} wave={engine.FORCE_WAVE} rows={engine.FORCE_TILE_ROWS} wide={engine.FORCE_WIDE}"
         try:
             if args.dataset:

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--W", type=int, default=154)
     ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (data-dependent power / clock check)")
     ap.add_argument("--lib", default=None, help="load this build of the library instead of the product one (A/B copies, stamp builds)")
-    ap.add_argument("--wide", type=int, default=-1, help="nint_layer.wide of every layer (-1: the engine's choice)")
+    ap.add_argument("--wide", type=int, default=-1, help="nint_layer.wide of every layer: weight-gradient kernel family (-1: the engine's choice)")
     ap.add_argument("--tile-rows", type=int, default=0, help="force 4- or 8-row tiles for the gate / dgrad kernels")
     ap.add_argument("--split", type=int, default=1, help="issue the forward gate kernel as this many launches over image groups")
     args = ap.parse_args()
