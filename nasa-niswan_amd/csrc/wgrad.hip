@@ -347,6 +347,189 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- the 128-column kernel
+// Wide layers (round 4).  The 4-wave kernel above stages a 64-column dG tile and a 16/32-channel cat tile per 64 x (16*NTC*taps)
+// output block: 62 (5x5) to 137 (3x3) staged bytes per MFMA, and with every CU streaming two such workgroups the L2 -> LDS
+// staging rate itself (~25 GB/s per CU by LDS-DMA) is what the matrix pipe waits for; its waves also re-read the dG fragments
+// four times.  This kernel gives an 8-wave workgroup (one per CU, two waves per SIMD) a 128-gate-column x NCT-channel-tile
+// output block: wave (gh, ct, half) owns the 64 gate columns gh of channel tile ct for a contiguous range of taps -- 4 row tiles
+// x 9 columns (3x3: 4 channel tiles), 4 x 13 (5x5: 2 channel tiles, taps 13 + 12), 4 x 13 (7x7: 1 channel tile) -- so a dG tile
+// serves NCT channel tiles and a cat tile both gate halves: 35 (5x5) / 59 (3x3) staged bytes per MFMA and 0.65 / 0.72 instead
+// of 0.79 / 0.9 transposed reads per MFMA.  Tap ranges are compile-time per wave role (switch on `half`), so every fragment
+// address is `per-lane base + immediate`, as above.  Partials leave in the layout of the 4-wave kernel with NTC = 1, so the
+// fold kernel and the workspace arithmetic are shared.  bf16 storage only (f32 mode is not the throughput mode).
+template <int KS, int NCT> struct WgWide {
+  static constexpr int taps = KS * KS;
+  static constexpr int HG = KS == 3 ? 1 : (KS == 5 ? 2 : 4);         // column groups per channel tile
+  static constexpr int JW = (taps + HG - 1) / HG;                   // taps per wave: 9, 13, 13
+  static constexpr int NVL = taps - (HG - 1) * JW;                  // taps of the last group: 9, 12, 10
+  static constexpr int JWA = JW + (NVL == JW ? 1 : 0);              // accumulator columns (the last group keeps one free for db)
+  static constexpr int NW = 2 * NCT * HG;                           // waves
+  static constexpr int PR = 4, RA = 288;                            // pixel rows per tile; bytes per dG pixel row (256 + 32 pad)
+  static constexpr int RB = NCT == 4 ? 160 : (NCT == 2 ? 96 : 32);  // bytes per cat halo pixel (conflict-free strides)
+  static constexpr int p = KS / 2, HWt = 32 + 2 * p, HHt = PR + 2 * p;
+  static constexpr int UA_ROW = RA / 16, NA_U = PR * 32 * UA_ROW;
+  static constexpr int UB_PIX = RB / 16, NB_U = HHt * HWt * UB_PIX, NB_U_PAD = (NB_U + 63) / 64 * 64;
+  static constexpr int a_bytes = PR * 32 * RA, b_bytes = NB_U_PAD * 16, buf_bytes = a_bytes + b_bytes;
+  static constexpr int NI_A = NA_U / 64, NI_B = NB_U_PAD / 64, NI = NI_A + NI_B;
+  static constexpr int NI_W = (NI + NW - 1) / NW;                   // DMA pieces per wave and tile
+  static_assert(NA_U % 64 == 0, "whole DMA pieces");
+  static_assert(NW == 8, "eight waves: two per SIMD");
+};
+
+template <int KS, int NCT>
+__global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgradArgs a) {
+  typedef WgWide<KS, NCT> G;
+  constexpr int PR = G::PR, RA = G::RA, RB = G::RB, HWt = G::HWt, HHt = G::HHt, p = G::p, JW = G::JW, JWA = G::JWA, HG = G::HG;
+  constexpr int a_bytes = G::a_bytes, buf_bytes = G::buf_bytes, NI_A = G::NI_A, NI = G::NI, NI_W = G::NI_W;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gh = wave & 1, cgi = wave >> 1, ct = cgi / HG, half = cgi % HG;
+  const WgSrc& T = a.s[0];
+  const int CBW = T.CB / NCT;                               // channel groups of NCT tiles (T.CB counts 16-channel tiles)
+  const int by = blockIdx.y;
+  const int nbw = __builtin_amdgcn_readfirstlane(by / CBW), cbw = __builtin_amdgcn_readfirstlane(by % CBW);
+  const int t_begin = blockIdx.x * T.tiles_per_split;
+  const int t_end = min(T.ntiles, t_begin + T.tiles_per_split);
+
+  f32x4_t acc[4][JWA];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < JWA; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // bias gradient: channel tile 0 of the source that carries it, on the waves of the last tap group (free accumulator column)
+  const bool do_db = __builtin_amdgcn_readfirstlane((T.want_db && cbw == 0 && ct == 0 && half == HG - 1) ? 1 : 0);
+
+  // DMA pieces of a tile: piece t = wave + NW * i (dealt round-robin: every wave has the same matrix work here)
+  unsigned doff[NI_W];
+#pragma unroll
+  for (int i = 0; i < NI_W; ++i) {
+    const int t = wave + G::NW * i;
+    unsigned o = 0;
+    if (t < NI_A) {
+      const int u = t * 64 + lane;
+      const int pix = u / G::UA_ROW, q = u - pix * G::UA_ROW;
+      if (q < 16) o = (unsigned)(((pix >> 5) * a.Wh + (pix & 31)) * a.dG_pix_stride + q * 16);
+    } else if (t < NI) {
+      const int u = (t - NI_A) * 64 + lane;
+      const int hp = u / G::UB_PIX, q = u - hp * G::UB_PIX;
+      const int hy = hp / HWt, hx = hp - hy * HWt;
+      if (hp < HHt * HWt && q < 2 * NCT) o = (unsigned)((hy * a.Wh + hx) * T.src_pix_stride + q * 16);
+    }
+    doff[i] = o;
+  }
+  int ld_tx, ld_ty, ld_img;
+  {
+    const int r = t_begin / a.tiles_x;
+    ld_tx = t_begin - r * a.tiles_x;
+    ld_img = r / a.tiles_y;
+    ld_ty = r - ld_img * a.tiles_y;
+  }
+  const char* const ga0 = T.dG + nbw * 128 * 2;
+  const char* const gb0 = T.src + cbw * 16 * NCT * 2;
+  const long src_img_stride = T.src_img_stride;
+  const int src_pix_stride = T.src_pix_stride;
+  auto issue_dma = [&](char* buf) {
+    const int y0 = ld_ty * PR, x0 = ld_tx * 32;
+    const char* ga = ga0 + (long)ld_img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride;
+    const char* gb = gb0 + (long)ld_img * src_img_stride + ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * src_pix_stride;
+#pragma unroll
+    for (int i = 0; i < NI_W; ++i) {
+      const int t = wave + G::NW * i;              // wave-uniform
+      if (t < NI) {
+        const char* src = (t < NI_A ? ga : gb) + doff[i];
+        char* dst = buf + (t < NI_A ? t * 1024 : a_bytes + (t - NI_A) * 1024);
+        // (inline asm for the reason given in wgrad_kernel: the wait is ours, ahead of the tile's barrier)
+        unsigned keep;
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+      }
+    }
+    const bool wx = ld_tx + 1 == a.tiles_x;
+    const bool wy = wx && (ld_ty + 1 == a.tiles_y);
+    ld_tx = wx ? 0 : ld_tx + 1;
+    ld_ty = wy ? 0 : (wx ? ld_ty + 1 : ld_ty);
+    ld_img += wy ? 1 : 0;
+  };
+  if (t_begin < t_end) issue_dma(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p8 = (i16 & 3) * 8;
+  const int vA = (4 * g + q4) * RA + gh * 128 + p8;                   // row tile i: + i * 32
+  const int vB = a_bytes + (4 * g + q4) * RB + ct * 32 + p8;          // tap (ty, tx): + (ty * HWt + tx) * RB
+
+  auto run_tiles = [&](auto tap0c, auto nvc, auto dbc) __attribute__((always_inline)) {
+    constexpr int TAP0 = decltype(tap0c)::value, NV = decltype(nvc)::value;
+    constexpr bool DB = decltype(dbc)::value;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int cur = (tile - t_begin) & 1;
+      if (tile + 1 < t_end) issue_dma(smem + (cur ^ 1) * buf_bytes);   // the other buffer was last read before the previous barrier
+      const char* Ab = smem + cur * buf_bytes + vA;
+      const char* Bb = smem + cur * buf_bytes + vB;
+      auto read_tr = [&](const char* ad, int half_off) __attribute__((always_inline)) {
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ad + half_off));
+        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
+      };
+#pragma unroll
+      for (int pr = 0; pr < PR; ++pr) {
+        u32x4_t af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = read_tr(Ab + pr * 32 * RA + i * 32, 16 * RA);
+#pragma unroll
+        for (int jj = 0; jj < NV; ++jj) {
+          const int tap = TAP0 + jj, tyy = tap / KS, txx = tap - tyy * KS;
+          const u32x4_t bf = read_tr(Bb + (tyy * HWt + txx) * RB + pr * HWt * RB, 16 * RB);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf, acc[i][jj]);
+        }
+        if constexpr (DB) {
+          const u32x4_t ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][JWA - 1] = mma_step<NINT_BF16>(af[i], ones, acc[i][JWA - 1]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed ...
+      __syncthreads();                                   // ... for every wave, and this one is fully read
+    }
+  };
+  // wave roles: the tap range is a compile-time constant inside each instance of the tile loop
+  auto role = [&](auto hc) __attribute__((always_inline)) {
+    constexpr int H_ = decltype(hc)::value;
+    constexpr int TAP0 = H_ * JW, NV = H_ == HG - 1 ? G::NVL : JW;
+    if (H_ == HG - 1 && do_db) run_tiles(std::integral_constant<int, TAP0>{}, std::integral_constant<int, NV>{}, std::true_type{});
+    else run_tiles(std::integral_constant<int, TAP0>{}, std::integral_constant<int, NV>{}, std::false_type{});
+  };
+  if constexpr (HG == 1) role(std::integral_constant<int, 0>{});
+  else if constexpr (HG == 2) { if (half == 0) role(std::integral_constant<int, 0>{}); else role(std::integral_constant<int, 1>{}); }
+  else { if (half == 0) role(std::integral_constant<int, 0>{}); else if (half == 1) role(std::integral_constant<int, 1>{});
+         else if (half == 2) role(std::integral_constant<int, 2>{}); else role(std::integral_constant<int, 3>{}); }
+
+  // ---- flush in the 4-wave kernel's slab layout with NTC = 1: partial[split][(nb, cb)][tap][n'loc 64][c 16]
+  const int nb = 2 * nbw + gh, cb = cbw * NCT + ct;
+  float* out = T.partial + ((size_t)blockIdx.x * T.nblk + (size_t)nb * T.CB + cb) * T.JG * 1024;
+  const int tap0 = half * JW, nv = half == HG - 1 ? G::NVL : JW;
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    if (jj < nv) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(tap0 + jj) * 1024 + (i * 16 + 4 * g + r) * 16 + i16] = acc[i][jj][r];
+    }
+  }
+  if (do_db) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(T.JG - 1) * 1024 + (i * 16 + 4 * g + r) * 16 + i16] = acc[i][JWA - 1][r];
+  }
+}
+
 // Fold the split-K slabs of ONE source (x or h part) into dW (OIHW f32).  A workgroup owns 64 consecutive
 // elements of the slab layout [block][j][n'loc 64][c 16] (one 256-byte line per split, fully coalesced) and
 // spreads the splits over its blockDim/64 waves; the per-wave sums are folded through LDS.  The order is a
@@ -418,15 +601,28 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
 }
 
 // ------------------------------------------------------------------------------ host side
-struct WgPart { int NTC, J, JW, KX, CB, TG, JG, splits; };   // one source (x or h) of the reduction
+struct WgPart { int NTC, J, JW, KX, CB, TG, JG, splits; int wcols; };   // one source (x or h) of the reduction (wcols: workgroup columns of the 128-column kernel)
 struct WgPlan {
   WgPart part[2];
   int NB, tiles_x, tiles_y, ntiles;
   size_t off_h, total_floats;
   bool merged;            // both sources in ONE launch (narrow layers: the launches are bound by re-reading dG, and the x and h
                           // workgroups of a pixel range then share its tiles in L2)
+  int wide_nct;           // > 0: the 8-wave 128-column kernel with this many channel tiles per workgroup (wgrad_wide_kernel)
 };
 
+// The 128-column kernel holds a layer when both sources are unfolded bf16 slabs, the gate columns come in pairs of 64-column
+// blocks and the channel counts in whole channel groups (3x3: 64 channels, 5x5: 32, 7x7: 16).  nint_layer.wide: 1 = never, 2 / 0 = wherever held.
+static int wg_wide_nct(const nint_layer* ly, int dtype) {
+  if (dtype != NINT_BF16 || ly->wide == 1 || ly->xfold) return 0;
+  const int nct = ly->k == 3 ? 4 : 0;      // (5x5 / 7x7: 4 x 13 accumulator tiles per wave do not fit 256 registers yet)
+  if (!nct || (4 * ly->Ch16) % 128 || ly->Cxp % (16 * nct) || ly->Chp % (16 * nct)) return 0;
+  return nct;
+}
+
+#ifndef NINT_WG_MIN_TILES
+#define NINT_WG_MIN_TILES 8
+#endif
 static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_geom* g, WgPlan* pl) {
   if (ly->k != 1 && ly->k != 3 && ly->k != 5 && ly->k != 7) return NINT_E_SHAPE;
   pl->NB = 4 * ly->Ch16 / 64;
@@ -436,6 +632,29 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   pl->ntiles = g ? N * pl->tiles_x * pl->tiles_y : (1 << 30);
   if (n_cu <= 0) n_cu = 256;
   size_t floats[2];
+  pl->wide_nct = wg_wide_nct(ly, dtype);
+  if (pl->wide_nct) {
+    // one 8-wave workgroup per CU; partial slabs in the 4-wave kernel's layout with one channel tile per block (NTC = 1)
+    for (int q = 0; q < 2; ++q) {
+      WgPart& w = pl->part[q];
+      const int Cp = q == 0 ? ly->Cxp : ly->Chp;
+      w.KX = ly->k; w.NTC = 1; w.J = ly->k * ly->k; w.JW = 0; w.TG = 1;
+      w.JG = w.J + (q == 0 ? 1 : 0);
+      w.CB = Cp / 16;
+      w.wcols = (pl->NB / 2) * (w.CB / pl->wide_nct);
+      int s = nint_cdiv(n_cu, w.wcols);
+      if (s > pl->ntiles / NINT_WG_MIN_TILES) s = pl->ntiles / NINT_WG_MIN_TILES;
+      if (s < 1) s = 1;
+      s = nint_cdiv(pl->ntiles, nint_cdiv(pl->ntiles, s));
+      if (s >= 8) s -= s % 8;             // all workgroup columns of a split on one XCD (they share its dG / cat tiles in L2)
+      w.splits = s;
+      floats[q] = (size_t)w.splits * pl->NB * w.CB * w.JG * 1024;
+    }
+    pl->merged = false;
+    pl->off_h = floats[0];
+    pl->total_floats = floats[0] + floats[1];
+    return NINT_OK;
+  }
   for (int q = 0; q < 2; ++q) {
     WgPart& w = pl->part[q];
     const int Cp = q == 0 ? ly->Cxp : ly->Chp;
@@ -515,6 +734,18 @@ static int launch_wgrad(WgradArgs& a, int splits, int nblk, hipStream_t st) {
   return NINT_OK;
 }
 
+template <int KS, int NCT>
+static int launch_wgrad_wide(WgradArgs& a, int splits, int cols, hipStream_t st) {
+  typedef WgWide<KS, NCT> G;
+  const size_t lds = 2 * (size_t)G::buf_bytes;
+  if (lds > 160 * 1024) return NINT_E_LDS;
+  auto kern = wgrad_wide_kernel<KS, NCT>;
+  NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(splits, cols), dim3(512), lds, st, a);
+  NINT_LAUNCH_CHECK();
+  return NINT_OK;
+}
+
 // instantiated (kernel size, channel tiles, columns per wave, horizontal taps) combinations
 template <int DT>
 static int dispatch_wgrad(WgradArgs& a, const WgPart& w, int nblk, hipStream_t st) {
@@ -589,7 +820,11 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       S.tiles_per_split = S.ntiles > 0 ? nint_cdiv(S.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
       a.NTC = w.NTC; a.J = w.J; a.TG = w.TG;
       a.taps = ly->k * w.KX;
-      if (!pl.merged || part == 1) {           // separate launches per source, or both sources in one
+      if (pl.wide_nct) {                       // the 8-wave 128-column kernel, one launch per source
+        a.nparts = 1;
+        rc = ly->k == 3 ? launch_wgrad_wide<3, 4>(a, w.splits, w.wcols, st) : NINT_E_SHAPE;
+        if (rc != NINT_OK) return rc;
+      } else if (!pl.merged || part == 1) {    // separate launches per source, or both sources in one
         a.nparts = pl.merged ? 2 : 1;
         const int nblk = pl.merged ? a.s[0].nblk + a.s[1].nblk : S.nblk;
         rc = dtype == NINT_BF16 ? dispatch_wgrad<NINT_BF16>(a, w, nblk, st) : dispatch_wgrad<NINT_F32>(a, w, nblk, st);

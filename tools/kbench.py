@@ -38,10 +38,12 @@ def main():
     ap.add_argument("--lib", default=None, help="load this build of the library instead of the product one (A/B copies, stamp builds)")
     ap.add_argument("--wide", type=int, default=-1, help="nint_layer.wide of every layer: weight-gradient kernel family (-1: the engine's choice)")
     ap.add_argument("--tile-rows", type=int, default=0, help="force 4- or 8-row tiles for the gate / dgrad kernels")
+    ap.add_argument("--hidden", default="64,32,16", help="hidden widths of the three layers (BASELINE configs[3]: 128,128,128)")
+    ap.add_argument("--ks", default="5,3,3", help="kernel sizes of the three layers (configs[3]: 3,3,3)")
     ap.add_argument("--split", type=int, default=1, help="issue the forward gate kernel as this many launches over image groups")
     args = ap.parse_args()
     lib = pkg.load_library(args.lib) if args.lib else pkg.load_library()
-    hidden, ks = (64, 32, 16), (5, 3, 3)
+    hidden, ks = tuple(int(v) for v in args.hidden.split(",")), tuple(int(v) for v in args.ks.split(","))
     cfgs, cin = [], args.C
     for ch, k in zip(hidden, ks):
         cfgs.append(LayerCfg(cin, ch, k)); cin = ch
@@ -59,7 +61,7 @@ def main():
     eng.pack_weights(ws_w, ws_b)
     X = torch.randn(B, T, args.C, H, W, device="cuda") * (0.0 if args.zeros else 1.0)
     eng.forward(ws, X)       # fills every slab with realistic (random-data) values
-    for l in range(3):
+    for l in range(len(cfgs)):
         ws.dh[l].view(torch.bfloat16 if eng.es == 2 else torch.float32).normal_(); ws.dc[l].normal_()
     g, st = C.byref(ws.g), None
     es = eng.es
@@ -104,7 +106,7 @@ def main():
                                                C.c_void_p(ws.dG[l].data_ptr() + dgs), st) == 0
         run(f"pointwise{l}", pw, None, B * comp_px * ly.Ch16 * (9 * es + 16))   # gates+dG (ET), dh (ET), c_prev, c_new, dc r+w (f32)
     # fill dG for every t so that wgrad sees random data
-    for l in range(3):
+    for l in range(len(cfgs)):
         ws.dG[l].view(torch.bfloat16 if es == 2 else torch.float32).normal_(std=0.05)
     for l, cfg in enumerate(cfgs):
         ly = eng.layers[l]
@@ -122,7 +124,7 @@ def main():
         def fused(ly=ly, dgs=dgs, dx=dx, l=l, gs=gs, cs=cs):      # dgrad(t+1) + pointwise backward(t) in one launch
             assert lib.nint_cell_bwd_fused(C.byref(ly), g, eng.dt, B, C.c_void_p(ws.dG[l].data_ptr() + dgs), C.c_void_p(dx) if dx else None,
                                            C.c_void_p(ws.gates[l].data_ptr() + gs), C.c_void_p(ws.c[l].data_ptr() + cs),
-                                           C.c_void_p(ws.c[l].data_ptr() + 2 * cs), C.c_void_p(ws.dh[l].data_ptr()) if l < 2 else None,
+                                           C.c_void_p(ws.c[l].data_ptr() + 2 * cs), C.c_void_p(ws.dh[l].data_ptr()) if l < len(cfgs) - 1 else None,
                                            C.c_void_p(ws.dc[l].data_ptr()), C.c_void_p(ws.dG[l].data_ptr()), st) == 0
         run(f"fused{l}", fused, fl)
         dW = torch.empty(4 * cfg.Ch, cfg.Cx + cfg.Ch, cfg.k, cfg.k, device="cuda")
