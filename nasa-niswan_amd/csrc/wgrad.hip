@@ -382,6 +382,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgradArgs a) {
   typedef WgWide<KS, NCT> G;
   constexpr int PR = G::PR, RA = G::RA, RB = G::RB, HWt = G::HWt, HHt = G::HHt, p = G::p, JW = G::JW, JWA = G::JWA, HG = G::HG;
   constexpr int a_bytes = G::a_bytes, buf_bytes = G::buf_bytes, NI_A = G::NI_A, NI = G::NI, NI_W = G::NI_W;
+#ifndef NINT_WG_STREAM
+#define NINT_WG_STREAM (JW > 9)
+#endif
+  constexpr bool STREAM = NINT_WG_STREAM;     // 4 x 13 tiles: explicit two-deep fragment stream; 4 x 9: the compiler's schedule
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgradArgs a) {
   const int nbw = __builtin_amdgcn_readfirstlane(by / CBW), cbw = __builtin_amdgcn_readfirstlane(by % CBW);
   const int t_begin = blockIdx.x * T.tiles_per_split;
   const int t_end = min(T.ntiles, t_begin + T.tiles_per_split);
+  const unsigned src_pix_stride = (unsigned)T.src_pix_stride;
 
   f32x4_t acc[4][JWA];
 #pragma unroll
@@ -401,24 +406,23 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgradArgs a) {
   // bias gradient: channel tile 0 of the source that carries it, on the waves of the last tap group (free accumulator column)
   const bool do_db = __builtin_amdgcn_readfirstlane((T.want_db && cbw == 0 && ct == 0 && half == HG - 1) ? 1 : 0);
 
-  // DMA pieces of a tile: piece t = wave + NW * i (dealt round-robin: every wave has the same matrix work here)
-  unsigned doff[NI_W];
-#pragma unroll
-  for (int i = 0; i < NI_W; ++i) {
-    const int t = wave + G::NW * i;
+  // DMA pieces of a tile: piece t = wave + NW * i (dealt round-robin: every wave has the same matrix work here).  The per-lane
+  // source offset of a piece is recomputed when it is issued (a dozen VALU instructions between MFMAs): the 4 x 13 accumulator
+  // tile leaves no registers to keep NI_W of them.
+  auto piece_off = [&](int t) __attribute__((always_inline)) {
     unsigned o = 0;
     if (t < NI_A) {
-      const int u = t * 64 + lane;
-      const int pix = u / G::UA_ROW, q = u - pix * G::UA_ROW;
-      if (q < 16) o = (unsigned)(((pix >> 5) * a.Wh + (pix & 31)) * a.dG_pix_stride + q * 16);
-    } else if (t < NI) {
-      const int u = (t - NI_A) * 64 + lane;
-      const int hp = u / G::UB_PIX, q = u - hp * G::UB_PIX;
-      const int hy = hp / HWt, hx = hp - hy * HWt;
-      if (hp < HHt * HWt && q < 2 * NCT) o = (unsigned)((hy * a.Wh + hx) * T.src_pix_stride + q * 16);
+      const unsigned u = (unsigned)(t * 64 + lane);
+      const unsigned pix = __umulhi(u, (unsigned)(((1ull << 32) + G::UA_ROW - 1) / G::UA_ROW)), q = u - pix * G::UA_ROW;
+      o = q < 16 ? ((pix >> 5) * a.Wh + (pix & 31)) * a.dG_pix_stride + q * 16 : 0u;
+    } else {
+      const unsigned u = (unsigned)((t - NI_A) * 64 + lane);
+      const unsigned hp = __umulhi(u, (unsigned)(((1ull << 32) + G::UB_PIX - 1) / G::UB_PIX)), q = u - hp * G::UB_PIX;
+      const unsigned hy = __umulhi(hp, (unsigned)(((1ull << 32) + HWt - 1) / HWt)), hx = hp - hy * HWt;
+      o = (hp < (unsigned)(HHt * HWt) && q < 2u * NCT) ? (hy * a.Wh + hx) * src_pix_stride + q * 16 : 0u;
     }
-    doff[i] = o;
-  }
+    return o;
+  };
   int ld_tx, ld_ty, ld_img;
   {
     const int r = t_begin / a.tiles_x;
@@ -429,7 +433,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgradArgs a) {
   const char* const ga0 = T.dG + nbw * 128 * 2;
   const char* const gb0 = T.src + cbw * 16 * NCT * 2;
   const long src_img_stride = T.src_img_stride;
-  const int src_pix_stride = T.src_pix_stride;
   auto issue_dma = [&](char* buf) {
     const int y0 = ld_ty * PR, x0 = ld_tx * 32;
     const char* ga = ga0 + (long)ld_img * a.dG_img_stride + ((long)(y0 + a.P) * a.Wh + (x0 + a.P)) * a.dG_pix_stride;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgradArgs a) {
     for (int i = 0; i < NI_W; ++i) {
       const int t = wave + G::NW * i;              // wave-uniform
       if (t < NI) {
-        const char* src = (t < NI_A ? ga : gb) + doff[i];
+        const char* src = (t < NI_A ? ga : gb) + piece_off(t);
         char* dst = buf + (t < NI_A ? t * 1024 : a_bytes + (t - NI_A) * 1024);
         // (inline asm for the reason given in wgrad_kernel: the wait is ours, ahead of the tile's barrier)
         unsigned keep;
@@ -480,17 +483,42 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgradArgs a) {
         u32x4_t af[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = read_tr(Ab + pr * 32 * RA + i * 32, 16 * RA);
-#pragma unroll
-        for (int jj = 0; jj < NV; ++jj) {
+        auto colptr = [&](int jj) __attribute__((always_inline)) {
           const int tap = TAP0 + jj, tyy = tap / KS, txx = tap - tyy * KS;
-          const u32x4_t bf = read_tr(Bb + (tyy * HWt + txx) * RB + pr * HWt * RB, 16 * RB);
+          return Bb + (tyy * HWt + txx) * RB + pr * HWt * RB;
+        };
+        if constexpr (STREAM) {
+          // cat fragments STREAMED: two live at a time, the next column's reads issued ahead of this column's MFMAs (the
+          // compiler's own schedule hoists a whole row of them: 52 registers the 4 x 13 tile does not have)
+          u32x4_t bfq[2];
+          if constexpr (NV > 0) bfq[0] = read_tr(colptr(0), 16 * RB);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf, acc[i][jj]);
+          for (int jj = 0; jj < NV; ++jj) {
+            if (jj + 1 < NV) bfq[(jj + 1) & 1] = read_tr(colptr(jj + 1), 16 * RB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bfq[jj & 1], acc[i][jj]);
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < NV; ++jj) {
+            const u32x4_t bf = read_tr(colptr(jj), 16 * RB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][jj] = mma_step<NINT_BF16>(af[i], bf, acc[i][jj]);
+          }
         }
         if constexpr (DB) {
           const u32x4_t ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[i][JWA - 1] = mma_step<NINT_BF16>(af[i], ones, acc[i][JWA - 1]);
+        }
+        if constexpr (STREAM) {
+          __builtin_amdgcn_sched_group_barrier(0x100, NV > 0 ? 10 : 8, 0);
+#pragma unroll
+          for (int jj = 0; jj < NV; ++jj) {
+            if (jj + 1 < NV) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          }
+          if constexpr (DB) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed ...
@@ -615,7 +643,7 @@ struct WgPlan {
 // blocks and the channel counts in whole channel groups (3x3: 64 channels, 5x5: 32, 7x7: 16).  nint_layer.wide: 1 = never, 2 / 0 = wherever held.
 static int wg_wide_nct(const nint_layer* ly, int dtype) {
   if (dtype != NINT_BF16 || ly->wide == 1 || ly->xfold) return 0;
-  const int nct = ly->k == 3 ? 4 : 0;      // (5x5 / 7x7: 4 x 13 accumulator tiles per wave do not fit 256 registers yet)
+  const int nct = ly->k == 3 ? 4 : (ly->k == 5 ? 2 : (ly->k == 7 ? 1 : 0));
   if (!nct || (4 * ly->Ch16) % 128 || ly->Cxp % (16 * nct) || ly->Chp % (16 * nct)) return 0;
   return nct;
 }
@@ -822,7 +850,8 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       a.taps = ly->k * w.KX;
       if (pl.wide_nct) {                       // the 8-wave 128-column kernel, one launch per source
         a.nparts = 1;
-        rc = ly->k == 3 ? launch_wgrad_wide<3, 4>(a, w.splits, w.wcols, st) : NINT_E_SHAPE;
+        rc = ly->k == 3 ? launch_wgrad_wide<3, 4>(a, w.splits, w.wcols, st)
+           : (ly->k == 5 ? launch_wgrad_wide<5, 2>(a, w.splits, w.wcols, st) : launch_wgrad_wide<7, 1>(a, w.splits, w.wcols, st));
         if (rc != NINT_OK) return rc;
       } else if (!pl.merged || part == 1) {    // separate launches per source, or both sources in one
         a.nparts = pl.merged ? 2 : 1;

@@ -10,11 +10,13 @@ split into the two things that can actually go wrong:
   (2) the SUMMANDS: the stored dG slab against the oracle's dG (the gradient of the pre-activation gates), elementwise.
 
 What is left between db and the oracle's db is then a sum of per-pixel errors of dG (each within the elementwise gate)
-that do not add coherently, against a sum that cancels: |err| <~ gate * ||dG_col||_2, which the last assertion writes
-down -- it is the justified form of the fuzz tool's bias gate (tools/fuzz_shapes.py: check_bias_grad).
+against a sum that cancels.  Those errors are partly coherent -- the bf16 rounding of one weight moves a whole column the
+same way -- so the only honest bound is the coherent one, |err| <= gate * ||dG_col||_1, which the last assertion writes
+down (the incoherent estimate gate * ||dG_col||_2 is printed beside it: the fuzz screen has seen 10 x that).  It is the
+justified form of the fuzz tool's bias gate (tools/fuzz_shapes.py: check_bias_grad).
 
 Tolerances: (1) |db - colsum| <= 1e-5 * max|colsum| per layer (measured: see the printed lines); (2) rel-L2 <= 2e-2 per
-(layer, t) in bf16, max-abs <= 1e-4 * max in f32; (3) |db - db_oracle| <= 3e-2 * ||dG_col||_2 + 3e-2 * |db_oracle| (bf16)."""
+(layer, t) in bf16, max-abs <= 1e-4 * max in f32; (3) |db - db_oracle| <= 3e-2 * ||dG_col||_1 (bf16)."""
 import numpy as np
 import pytest
 import torch
@@ -102,15 +104,15 @@ def test_bias_gradient_is_the_sum_of_the_stored_dG_and_the_stored_dG_is_the_orac
         # (3) what is left: a sum of independent roundings against a cancelling sum
         dbo = leaf[f"layers.{l}.conv.bias"].grad.double()
         dGo = torch.cat([pre[(l, t)].grad.double() for t in range(T)])
-        l2col = dGo.pow(2).sum(dim=(0, 2, 3)).sqrt()
+        l2col, l1col = dGo.pow(2).sum(dim=(0, 2, 3)).sqrt(), dGo.abs().sum(dim=(0, 2, 3))
         e3 = (db - dbo).abs()
         rel3 = float((db - dbo).norm() / dbo.norm())
-        cancel = float((l2col.norm()) / dbo.norm())
+        cancel = float((l1col.norm()) / dbo.norm())
         print(f"  {dtype} layer {l}: |db - colsum(stored dG)| / max = {e1:.2e};  stored dG vs oracle {worst:.2e};  "
-              f"db vs oracle rel-L2 {rel3:.2e}  (||dG_col||_2 / |db| = {cancel:.1f})")
+              f"db vs oracle rel-L2 {rel3:.2e}  (||dG_col||_1 / |db| = {cancel:.1f}; worst |err| / (3e-2 ||dG_col||_2) = {float((e3 / (3e-2 * l2col)).max()):.2f})")
         assert e1 <= 1e-5, (l, e1)
         if dtype == "f32":
             assert float(e3.max() / dbo.abs().max()) <= 1e-3, l
         else:
-            bound = 3e-2 * l2col + 3e-2 * dbo.abs()
+            bound = 3e-2 * l1col
             assert bool((e3 <= bound).all()), (l, float((e3 / bound).max()))

@@ -22,6 +22,11 @@ SHAPES = {
     "64-64-ragged": (64, 64, 3, 6, 21, 45),
     "128-64-tiny-grid": (128, 64, 3, 3, 7, 33),
     "64-128-one-image": (64, 128, 3, 1, 50, 154),
+    "bench-layer0-62-64-k5": (62, 64, 5, 3, 28, 77),
+    "32-32-k5-ragged": (32, 32, 5, 5, 13, 41),
+    "126-64-k5": (126, 64, 5, 2, 22, 64),
+    "16-32-k7": (16, 32, 7, 3, 19, 50),
+    "62-64-k7": (62, 64, 7, 2, 12, 35),
 }
 
 
@@ -92,7 +97,7 @@ def test_both_weight_gradient_families_reduce_the_same_slabs_to_the_f64_sum(lib,
     eng.release(ws)
 
 
-def test_the_library_picks_the_128_column_kernel_for_wide_3x3_layers_only(lib):
+def test_the_library_picks_the_128_column_kernel_where_it_is_instantiated(lib):
     """Host arithmetic of the choice, read off the workspace size (the two families size their split-K slabs differently):
     wide = 0 equals wide = 2 where the 8-wave kernel is instantiated and wide = 1 everywhere else."""
     from nasa_niswan_amd._lib import NintLayer, NINT_BF16, NINT_F32
@@ -106,7 +111,8 @@ def test_the_library_picks_the_128_column_kernel_for_wide_3x3_layers_only(lib):
         return lib.nint_wgrad_workspace_bytes(C.byref(ly), dt, 256)
 
     for Cx, Ch, k, held in ((62, 128, 3, True), (128, 128, 3, True), (64, 64, 3, True), (64, 32, 3, False), (32, 16, 3, False),
-                            (62, 64, 5, False), (62, 64, 1, False)):
+                            (62, 64, 5, True), (126, 64, 5, True), (64, 32, 5, True), (64, 16, 5, False), (62, 64, 7, True),
+                            (62, 64, 1, False), (62, 48, 3, False)):
         b0, b1, b2 = (ws_bytes(Cx, Ch, k, w) for w in (0, 1, 2))
         assert b0 > 0 and b1 > 0 and b2 > 0
         assert (b0 == b2) and ((b2 != b1) == held), (Cx, Ch, k, b0, b1, b2)

@@ -30,19 +30,24 @@ def stored_dG(eng, ws, l):
 
 def check_bias_grad(tag, name, db, dbo, dG_stored, dG_oracle, dtype):
     """The bias gradient is a sum that cancels (tests/test_gpu_bias_grad.py): bf16 mode is gated on its two factors instead of
-    on a loose end-to-end figure -- (1) db equals the f32 column sum of the dG slab the kernels STORED (1e-5 of its max:
-    a dropped or doubled tile shows here whatever the cancellation), (2) what separates it from the oracle is a sum of
-    per-pixel errors of dG (the elementwise gate is 3e-2 rel-L2) that do not add coherently: |err| <= 3e-2 * ||dG_col||_2
-    + 3e-2 * |db|.  Returns the plain rel-L2 against the oracle for the log (worst seen: 7.7e-2, a B = 1, T = 1 top layer)."""
-    db, dbo = db.double(), dbo.double()
+    on a loose end-to-end figure -- (1) the REDUCTION: db equals the f32 column sum of the dG slab the kernels STORED (1e-5 of
+    its max: a dropped or doubled tile shows here whatever the cancellation); (2) the SUMMANDS: the stored slab against the
+    oracle's dG, elementwise (rel-L2 <= 3e-2, the gate of every other gradient).  What is then left between db and the oracle's
+    db is a sum of per-element errors that are partly coherent (the bf16 rounding of one weight moves a whole column the same
+    way), so its only honest bound is the coherent one, (3) |err| <= 3e-2 * ||dG_col||_1 -- measured up to 10 x the
+    incoherent estimate 3e-2 * ||dG_col||_2 (fuzz seed 11 #9: 128 hidden channels, 7x7, 17 x 14 grid).  Returns the plain
+    rel-L2 against the oracle for the log (worst seen: 7.7e-2, a B = 1, T = 1 top layer)."""
+    db, dbo, go = db.double(), dbo.double(), dG_oracle.double()
     if dG_stored is not None:
-        colsum = dG_stored.double().sum(dim=(0, 2, 3))
+        gs = dG_stored.double()
+        colsum = gs.sum(dim=(0, 2, 3))
         e1 = float((db - colsum).abs().max() / (colsum.abs().max() + 1e-30))
         assert e1 <= 1e-5, (tag, name, "bias gradient is not the column sum of the stored dG slab", e1)
-    l2col = dG_oracle.double().pow(2).sum(dim=(0, 2, 3)).sqrt()
-    bound = 3e-2 * l2col + 3e-2 * dbo.abs() + 1e-30
+        e2 = float((gs - go).norm() / (go.norm() + 1e-30))
+        assert e2 <= 3e-2, (tag, name, "stored dG slab against the oracle's dG", e2)
+    bound = 3e-2 * go.abs().sum(dim=(0, 2, 3)) + 1e-30
     worst = float(((db - dbo).abs() / bound).max())
-    assert worst <= 1.0, (tag, name, "bias gradient outside the cancellation bound", worst)
+    assert worst <= 1.0, (tag, name, "bias gradient outside the coherent-error bound", worst)
     return float((db - dbo).norm() / (dbo.norm() + 1e-30))
 
 
