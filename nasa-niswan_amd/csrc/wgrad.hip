@@ -629,22 +629,23 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
 }
 
 // ------------------------------------------------------------------------------ host side
-struct WgPart { int NTC, J, JW, KX, CB, TG, JG, splits; int wcols; };   // one source (x or h) of the reduction (wcols: workgroup columns of the 128-column kernel)
+struct WgPart { int NTC, J, JW, KX, CB, TG, JG, splits;   // one source (x or h) of the reduction
+                int wide_nct, wcols; };                     // > 0: the 8-wave 128-column kernel with this many channel tiles per workgroup (wgrad_wide_kernel); its workgroup columns
 struct WgPlan {
   WgPart part[2];
   int NB, tiles_x, tiles_y, ntiles;
   size_t off_h, total_floats;
   bool merged;            // both sources in ONE launch (narrow layers: the launches are bound by re-reading dG, and the x and h
                           // workgroups of a pixel range then share its tiles in L2)
-  int wide_nct;           // > 0: the 8-wave 128-column kernel with this many channel tiles per workgroup (wgrad_wide_kernel)
 };
 
-// The 128-column kernel holds a layer when both sources are unfolded bf16 slabs, the gate columns come in pairs of 64-column
-// blocks and the channel counts in whole channel groups (3x3: 64 channels, 5x5: 32, 7x7: 16).  nint_layer.wide: 1 = never, 2 / 0 = wherever held.
-static int wg_wide_nct(const nint_layer* ly, int dtype) {
-  if (dtype != NINT_BF16 || ly->wide == 1 || ly->xfold) return 0;
+// The 128-column kernel holds a SOURCE (x or h) of a layer when it is an unfolded bf16 slab, the gate columns come in pairs of
+// 64-column blocks and the source's channels in whole channel groups (3x3: 64 channels, 5x5: 32, 7x7: 16) -- the reference
+// stack's second layer (64 -> 32, 3x3) takes it for its x source only.  nint_layer.wide: 1 = never, 2 / 0 = wherever held.
+static int wg_wide_nct(const nint_layer* ly, int dtype, int q) {
+  if (dtype != NINT_BF16 || ly->wide == 1 || (q == 0 && ly->xfold)) return 0;
   const int nct = ly->k == 3 ? 4 : (ly->k == 5 ? 2 : (ly->k == 7 ? 1 : 0));
-  if (!nct || (4 * ly->Ch16) % 128 || ly->Cxp % (16 * nct) || ly->Chp % (16 * nct)) return 0;
+  if (!nct || (4 * ly->Ch16) % 128 || (q == 0 ? ly->Cxp : ly->Chp) % (16 * nct)) return 0;
   return nct;
 }
 
@@ -660,16 +661,17 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   pl->ntiles = g ? N * pl->tiles_x * pl->tiles_y : (1 << 30);
   if (n_cu <= 0) n_cu = 256;
   size_t floats[2];
-  pl->wide_nct = wg_wide_nct(ly, dtype);
-  if (pl->wide_nct) {
-    // one 8-wave workgroup per CU; partial slabs in the 4-wave kernel's layout with one channel tile per block (NTC = 1)
-    for (int q = 0; q < 2; ++q) {
-      WgPart& w = pl->part[q];
-      const int Cp = q == 0 ? ly->Cxp : ly->Chp;
+  for (int q = 0; q < 2; ++q) {
+    WgPart& w = pl->part[q];
+    const int Cp = q == 0 ? ly->Cxp : ly->Chp;
+    w.wide_nct = wg_wide_nct(ly, dtype, q);
+    w.wcols = 0;
+    if (w.wide_nct) {
+      // one 8-wave workgroup per CU; partial slabs in the 4-wave kernel's layout with one channel tile per block (NTC = 1)
       w.KX = ly->k; w.NTC = 1; w.J = ly->k * ly->k; w.JW = 0; w.TG = 1;
       w.JG = w.J + (q == 0 ? 1 : 0);
       w.CB = Cp / 16;
-      w.wcols = (pl->NB / 2) * (w.CB / pl->wide_nct);
+      w.wcols = (pl->NB / 2) * (w.CB / w.wide_nct);
       int s = nint_cdiv(n_cu, w.wcols);
       if (s > pl->ntiles / NINT_WG_MIN_TILES) s = pl->ntiles / NINT_WG_MIN_TILES;
       if (s < 1) s = 1;
@@ -677,15 +679,8 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
       if (s >= 8) s -= s % 8;             // all workgroup columns of a split on one XCD (they share its dG / cat tiles in L2)
       w.splits = s;
       floats[q] = (size_t)w.splits * pl->NB * w.CB * w.JG * 1024;
+      continue;
     }
-    pl->merged = false;
-    pl->off_h = floats[0];
-    pl->total_floats = floats[0] + floats[1];
-    return NINT_OK;
-  }
-  for (int q = 0; q < 2; ++q) {
-    WgPart& w = pl->part[q];
-    const int Cp = q == 0 ? ly->Cxp : ly->Chp;
     w.KX = (q == 0 && ly->xfold) ? 1 : ly->k;           // folded x source: vertical taps only
     const int taps = ly->k * w.KX;
     w.NTC = (taps * 2 <= 20 && Cp % 32 == 0) ? 2 : 1;   // channel tiles per column block
@@ -717,7 +712,7 @@ static int wg_plan(const nint_layer* ly, int dtype, int n_cu, int N, const nint_
   }
   // same kernel shape for both sources and few workgroup columns: one launch, one split count
   const WgPart &wx = pl->part[0], &wh = pl->part[1];
-  pl->merged = wx.NTC == wh.NTC && wx.JW == wh.JW && wx.KX == wh.KX && wx.TG == 1 && wh.TG == 1 && pl->NB * (wx.CB + wh.CB) <= 8;
+  pl->merged = !wx.wide_nct && !wh.wide_nct && wx.NTC == wh.NTC && wx.JW == wh.JW && wx.KX == wh.KX && wx.TG == 1 && wh.TG == 1 && pl->NB * (wx.CB + wh.CB) <= 8;
   if (pl->merged) {
     int s = nint_cdiv(2 * n_cu, pl->NB * (wx.CB + wh.CB));
     if (s > pl->ntiles / NINT_WG_MIN_TILES) s = pl->ntiles / NINT_WG_MIN_TILES;
@@ -848,7 +843,7 @@ int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom
       S.tiles_per_split = S.ntiles > 0 ? nint_cdiv(S.ntiles, w.splits) : 1;   // spread what is there evenly over the planned splits
       a.NTC = w.NTC; a.J = w.J; a.TG = w.TG;
       a.taps = ly->k * w.KX;
-      if (pl.wide_nct) {                       // the 8-wave 128-column kernel, one launch per source
+      if (w.wide_nct) {                        // the 8-wave 128-column kernel, one launch per source
         a.nparts = 1;
         rc = ly->k == 3 ? launch_wgrad_wide<3, 4>(a, w.splits, w.wcols, st)
            : (ly->k == 5 ? launch_wgrad_wide<5, 2>(a, w.splits, w.wcols, st) : launch_wgrad_wide<7, 1>(a, w.splits, w.wcols, st));

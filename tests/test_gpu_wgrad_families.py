@@ -22,6 +22,7 @@ SHAPES = {
     "64-64-ragged": (64, 64, 3, 6, 21, 45),
     "128-64-tiny-grid": (128, 64, 3, 3, 7, 33),
     "64-128-one-image": (64, 128, 3, 1, 50, 154),
+    "refstack-layer1-64-32-x-source-only": (64, 32, 3, 5, 26, 52),
     "bench-layer0-62-64-k5": (62, 64, 5, 3, 28, 77),
     "32-32-k5-ragged": (32, 32, 5, 5, 13, 41),
     "126-64-k5": (126, 64, 5, 2, 22, 64),
@@ -110,7 +111,7 @@ def test_the_library_picks_the_128_column_kernel_where_it_is_instantiated(lib):
         ly.Cxp, ly.Ch16, ly.Chp = rup(k * Cx if xfold else Cx, kc), rup(Ch, 16), rup(Ch, kc)
         return lib.nint_wgrad_workspace_bytes(C.byref(ly), dt, 256)
 
-    for Cx, Ch, k, held in ((62, 128, 3, True), (128, 128, 3, True), (64, 64, 3, True), (64, 32, 3, False), (32, 16, 3, False),
+    for Cx, Ch, k, held in ((62, 128, 3, True), (128, 128, 3, True), (64, 64, 3, True), (64, 32, 3, True), (32, 32, 3, False), (32, 16, 3, False),
                             (62, 64, 5, True), (126, 64, 5, True), (64, 32, 5, True), (64, 16, 5, False), (62, 64, 7, True),
                             (62, 64, 1, False), (62, 48, 3, False)):
         b0, b1, b2 = (ws_bytes(Cx, Ch, k, w) for w in (0, 1, 2))
