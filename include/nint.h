@@ -186,6 +186,12 @@ int nint_cell_fwd(const nint_layer* ly /*host*/, const nint_geom* g /*host*/, in
                   const void* x_slab, const void* h_prev, const float* c_prev,
                   void* h_out, float* c_out, void* gates_out, void* stream);
 
+/* 1 when nint_cell_fwd runs this layer on the vector-ALU STENCIL kernel (csrc/stencil.hip) instead of the implicit-GEMM one:
+ * tiny hidden widths (Ch <= 8: at most 32 gate columns, no dense contraction), k = 3, thin input (<= 16 channels, or a folded
+ * first-layer input of <= 64 folded channels), tile_rows == 0.  One lane per pixel, LDS-staged halo tile, DPP row shifts for
+ * the horizontal taps, scalar-operand weights, the same LSTM epilogue.  Pure host arithmetic. */
+int nint_stencil_holds(const nint_layer* ly /*host*/);
+
 /* autograd backward of model.py:223-229 (pointwise part): consumes dh, dc (in place -> dc_prev),
  * the stashed gates and c_prev / c_new; writes pre-activation gate grads into the dG halo slab. */
 int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "nint_pack_weights_layers": (_I, [C.POINTER(vp), C.POINTER(vp), C.POINTER(NintLayer), _I, _I, vp]),
     "nint_pack_btchw_xfold": (_I, [vp, vp, _I, _I, _I, _I, _I, _PG, _I, vp]),
     "nint_unfold_dx": (_I, [vp, vp, _I, _I, _I, _I, _I, _I, _I, vp]),
+    "nint_stencil_holds": (_I, [_PL]),
     "nint_cell_fwd": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
     "nint_cell_bwd_pointwise": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp, vp, vp, vp]),
     "nint_conv_dgrad": (_I, [_PL, _PG, _I, _I, vp, vp, vp, vp]),

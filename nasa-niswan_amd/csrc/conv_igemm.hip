@@ -892,6 +892,12 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
   a.tile_rows = ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
   if (ly->wide < 0 || ly->wide > 2) return NINT_E_ARG;   // (the weight-gradient family switch: nothing to do with this launch)
+  // tiny hidden widths (4*Ch <= 32 gate columns: no dense contraction): the VALU stencil kernel (csrc/stencil.hip), unless the
+  // tile height is pinned; a planned launch (merged grids) has no stencil form: the caller then enqueues it by itself
+  if (nint_internal_stencil_holds(ly)) {
+    if (plan) return NINT_E_SHAPE;
+    return nint_internal_stencil_lstm(ly, g, dtype, N, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
+  }
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st, plan)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st, plan);
 }

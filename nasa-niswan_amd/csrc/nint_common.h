@@ -175,6 +175,22 @@ struct WgJob {           // one layer's weight / bias gradient
 };
 int nint_internal_conv_wgrad_multi(const WgJob* jobs, int njobs, const nint_geom* g, int dtype, float* partial,
                                    size_t partial_bytes, int n_cu, void* stream, Probe* probe = nullptr);
+// stencil.hip: the gate step of tiny hidden widths (Ch <= 8, 3x3) on the vector ALU.  Its weight image -- one row of 32 f32 per
+// (tap, channel) in the kernel's iteration order -- sits behind the MFMA images in the Wf buffer (nint_pack_weights).
+__host__ __device__ inline bool nint_stencil_shape(int Cx, int Ch, int k, int xfold) {
+  return k == 3 && Ch <= 8 && (xfold ? 3 * Cx <= 64 : Cx <= 16);
+}
+__host__ __device__ inline int nint_stencil_rows(int Cx, int Ch, int xfold) {     // rows per vertical tap: x part + h part
+  return (xfold ? 4 * nint_cdiv(3 * Cx, 4) : 12 * nint_cdiv(Cx, 4)) + 12 * nint_cdiv(Ch, 4);
+}
+__host__ __device__ inline size_t nint_internal_stencil_offset(int Cxp, int Chp, int Ch16, int k, int dtype) {
+  const size_t img = (size_t)(Cxp + Chp) * 4 * Ch16 * k * k * (dtype == NINT_BF16 ? 2 : 4);    // both MFMA images fit in this
+  return (img + 255) / 256 * 256;
+}
+bool nint_internal_stencil_holds(const nint_layer* ly);
+int nint_internal_stencil_lstm(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* x_slab,
+                               const void* h_prev, const float* c_prev, void* h_out, float* c_out, void* gates_out,
+                               void* stream);
 #define NINT_MULTI_MAX 4  // problems per merged grid (conv_lstm_multi_kernel / conv_bwd_multi_kernel)
 struct CellFwdJob {      // one gate launch (nint_cell_fwd's arguments)
   const nint_layer* ly; const void* x_slab; const void* h_prev; const float* c_prev; void* h_out; float* c_out; void* gates_out;

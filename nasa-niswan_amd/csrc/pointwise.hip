@@ -315,8 +315,34 @@ __device__ __forceinline__ void pack_weights_body(const float* __restrict__ W, c
   const int sd = 4 * Ch16 / E::KC * taps;
   const size_t nd = (size_t)sd * ntd * 64 * E::EPL;
   const size_t nb = 4 * Ch16;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nf + nd + nb; i += (size_t)gridDim.x * blockDim.x) {
-    if (i < nf) {
+  // stencil image (csrc/stencil.hip; tiny hidden widths): rows of 32 f32, row order = the kernel's iteration order
+  //   for ky: [x source: per channel quad q: (plain) kx = 0, 1, 2 x 4 channels | (folded) 4 folded channels]  [h source: per quad: kx x 4]
+  // column o = gate*8 + ch; values rounded to the storage type like the MFMA images
+  const bool st = nint_stencil_shape(Cx, Ch, k, xfold);
+  const int rpk = st ? nint_stencil_rows(Cx, Ch, xfold) : 0;
+  const size_t ns = (size_t)3 * rpk * 32;
+  float* Ws = (float*)((char*)Wf + nint_internal_stencil_offset(Cxp, Chp, Ch16, k, DT));
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nf + nd + nb + ns; i += (size_t)gridDim.x * blockDim.x) {
+    if (i >= nf + nd + nb) {
+      const size_t ii = i - nf - nd - nb;
+      const int o = ii % 32, gate = o >> 3, ch = o & 7;
+      int r = (int)(ii / 32);
+      const int ky = r / rpk; r -= ky * rpk;
+      const int rx = xfold ? 4 * nint_cdiv(3 * Cx, 4) : 12 * nint_cdiv(Cx, 4);
+      int ic = -1, kx = 0;
+      if (r < rx) {
+        if (xfold) { if (r < 3 * Cx) { kx = r / Cx; ic = r % Cx; } }
+        else { const int q = r / 12, kk = (r % 12) / 4, e = r % 4; kx = kk; if (4 * q + e < Cx) ic = 4 * q + e; }
+      } else {
+        const int rh = r - rx, q = rh / 12, e = rh % 4;
+        kx = (rh % 12) / 4;
+        if (4 * q + e < Ch) ic = Cx + 4 * q + e;
+      }
+      float v = 0.f;
+      if (ic >= 0 && ch < Ch) v = W[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + ky * k + kx];
+      if (DT == NINT_BF16) v = bf2f(f2bf(v));
+      Ws[ii] = v;
+    } else if (i < nf) {
       const int e = i % E::EPL;
       size_t r = i / E::EPL;
       const int lane = r % 64; r /= 64;
@@ -414,8 +440,11 @@ extern "C" size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int
   if (kc < 0) return 0;
   const int es = dtype == NINT_BF16 ? 2 : 4;
   const int Cxp = nint_round_up(xfold ? k * Cx : Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
-  // both images fit in (Cxp+Chp) x 4*Ch16 x taps elements (the folded forward image is smaller)
-  return (size_t)(Cxp + Chp) * 4 * Ch16 * k * k * es;
+  // both images fit in (Cxp+Chp) x 4*Ch16 x taps elements (the folded forward image is smaller); tiny hidden widths keep the
+  // stencil kernel's f32 weight rows behind them (csrc/stencil.hip)
+  size_t n = (size_t)(Cxp + Chp) * 4 * Ch16 * k * k * es;
+  if (nint_stencil_shape(Cx, Ch, k, xfold)) n = nint_internal_stencil_offset(Cxp, Chp, Ch16, k, dtype) + (size_t)3 * nint_stencil_rows(Cx, Ch, xfold) * 128;
+  return n;
 }
 
 extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, void* Wd, float* bias_p, int Cx,
@@ -424,7 +453,7 @@ extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, vo
   const int kc = nint_kc(dtype);
   if (kc < 0) return NINT_E_ARG;
   const int Cxp = nint_round_up(xfold ? k * Cx : Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
-  const size_t n = 2 * (size_t)(Cxp + Chp) * 4 * Ch16 * k * k + 4 * Ch16;
+  const size_t n = 2 * (size_t)(Cxp + Chp) * 4 * Ch16 * k * k + 4 * Ch16 + 3 * 32 * (size_t)(nint_stencil_shape(Cx, Ch, k, xfold) ? nint_stencil_rows(Cx, Ch, xfold) : 0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == NINT_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<NINT_BF16>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k, xfold);
@@ -448,7 +477,8 @@ extern "C" int nint_pack_weights_layers(const float* const* W, const float* cons
         ly.Ch16 != nint_round_up(ly.Ch, 16))
       return NINT_E_ARG;
     t.e[l] = PackEntry{W[l], bias[l], (void*)ly.Wf, (void*)ly.Wd, (float*)ly.bias_p, ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k, ly.xfold};
-    const size_t n = 2 * (size_t)(ly.Cxp + ly.Chp) * 4 * ly.Ch16 * ly.k * ly.k + 4 * ly.Ch16;
+    const size_t n = 2 * (size_t)(ly.Cxp + ly.Chp) * 4 * ly.Ch16 * ly.k * ly.k + 4 * ly.Ch16 +
+                     3 * 32 * (size_t)(nint_stencil_shape(ly.Cx, ly.Ch, ly.k, ly.xfold) ? nint_stencil_rows(ly.Cx, ly.Ch, ly.xfold) : 0);
     if (n > nmax) nmax = n;
   }
   dim3 grid = grid1d(nmax);
