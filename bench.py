@@ -162,7 +162,7 @@ def parse_args(argv=None):
     ap.add_argument("--wide", type=int, default=0, help="nint_layer.wide of every layer: weight-gradient kernel family (0 = the library's choice, 1 = 4-wave 64-column kernel, 2 = 8-wave 128-column kernel where instantiated)")
     ap.add_argument("--wave", type=int, default=-1, choices=[-1, 0, 1],
                     help="forward (t, layer) wavefront, one grid per step (nint_seq.wave): -1 = the engine's rule (small batches), 0 = off, 1 = on")
-    ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape)")
+    ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 1, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape; 1 = the stencil gate kernel where it holds)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--lib", default=None, help="load this build of the library (A/B copies made by nasa-niswan_amd/build.py --out=...) instead of the product one")

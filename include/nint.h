@@ -59,7 +59,8 @@ typedef struct nint_layer {
   int32_t Cx, Cxp;        /* input channels / padded to KC */
   int32_t Ch, Ch16, Chp;  /* hidden channels / padded to 16 / padded to KC */
   int32_t k;              /* odd kernel size, padding k/2 (model.py:204) */
-  int32_t tile_rows;      /* rows of the gate / dgrad kernels' pixel tile: 0 = chosen per launch shape, or 4 / 8 */
+  int32_t tile_rows;      /* rows of the gate / dgrad kernels' pixel tile: 0 = chosen per launch shape, or 4 / 8; 1 = one pixel per
+                           * LANE: the vector-ALU stencil gate kernel (csrc/stencil.hip) where nint_stencil_holds(), else as 0 */
   int32_t xfold;          /* 1: the x source is HORIZONTALLY FOLDED (thin inputs, first layer only): slab channel
                            * kx*Cx + c holds x[.., x + kx - k/2][c] (0 outside the image), Cxp = roundup(k*Cx, KC), and
                            * the x part of K is k vertical taps x k*Cx channels instead of k*k taps x Cx channels padded
@@ -186,10 +187,10 @@ int nint_cell_fwd(const nint_layer* ly /*host*/, const nint_geom* g /*host*/, in
                   const void* x_slab, const void* h_prev, const float* c_prev,
                   void* h_out, float* c_out, void* gates_out, void* stream);
 
-/* 1 when nint_cell_fwd runs this layer on the vector-ALU STENCIL kernel (csrc/stencil.hip) instead of the implicit-GEMM one:
- * tiny hidden widths (Ch <= 8: at most 32 gate columns, no dense contraction), k = 3, thin input (<= 16 channels, or a folded
- * first-layer input of <= 64 folded channels), tile_rows == 0.  One lane per pixel, LDS-staged halo tile, DPP row shifts for
- * the horizontal taps, scalar-operand weights, the same LSTM epilogue.  Pure host arithmetic. */
+/* 1 when the vector-ALU STENCIL kernel (csrc/stencil.hip) holds this layer's gate step: tiny hidden widths (Ch <= 8: at most
+ * 32 gate columns, no dense contraction), k = 3, thin input (<= 16 channels, or a folded first-layer input of <= 64 folded
+ * channels).  nint_cell_fwd runs it for nint_layer.tile_rows == 1.  One lane per pixel, LDS-staged halo tile, DPP row
+ * shifts for the horizontal taps, scalar-operand weights, the same LSTM epilogue.  Pure host arithmetic. */
 int nint_stencil_holds(const nint_layer* ly /*host*/);
 
 /* autograd backward of model.py:223-229 (pointwise part): consumes dh, dc (in place -> dc_prev),

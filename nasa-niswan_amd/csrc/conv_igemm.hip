@@ -27,6 +27,12 @@
 
 enum { EPI_LSTM = 0, EPI_DGRAD = 1, EPI_DGRAD_PW = 2 };
 
+// The library's own choice between the stencil kernel and the padded MFMA tiles for layers both hold (tile_rows == 0).
+// Measured on the full 100 x 154 grid, B = 8, configs[0]'s layer (4 -> 8, 3x3): see DESIGN.md section 6.
+#ifndef NINT_STENCIL_AUTO
+#define NINT_STENCIL_AUTO(dtype) false
+#endif
+
 // MT (template) = row tiles per wave = rows of the pixel tile: 8 for the wide launches (one weight
 // stream per 128 pixels), 4 for the short-K launches of the narrow layers, whose time is all halo
 // fill + epilogue latency: smaller tiles put 3-4 workgroups per CU in flight instead of 2.
@@ -866,7 +872,7 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
   if (!ly || !g || !x_slab || !h_out || !c_out || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!(ly->k & 1) || ly->k / 2 > g->P) return NINT_E_ARG;
-  if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
+  if (ly->tile_rows != 0 && ly->tile_rows != 1 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
   if (!aligned16(x_slab) || !aligned16(h_prev) || !aligned16(ly->Wf) || !aligned16(h_out)) return NINT_E_ALIGN;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   if (ly->Cxp % kc || ly->Chp % kc || ly->Ch16 % 16 || ly->Chp < ly->Ch16) return NINT_E_ARG;
@@ -889,12 +895,13 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
   a.bias = ly->bias_p;
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = (char*)h_out; a.gates_out = (char*)gates_out;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
-  a.tile_rows = ly->tile_rows;
+  a.tile_rows = ly->tile_rows == 1 ? 0 : ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
   if (ly->wide < 0 || ly->wide > 2) return NINT_E_ARG;   // (the weight-gradient family switch: nothing to do with this launch)
-  // tiny hidden widths (4*Ch <= 32 gate columns: no dense contraction): the VALU stencil kernel (csrc/stencil.hip), unless the
-  // tile height is pinned; a planned launch (merged grids) has no stencil form: the caller then enqueues it by itself
-  if (nint_internal_stencil_holds(ly)) {
+  // tiny hidden widths (4*Ch <= 32 gate columns: no dense contraction): the VALU stencil kernel (csrc/stencil.hip) -- on request
+  // (nint_layer.tile_rows == 1: "one pixel per lane"), or where it measured faster than the padded MFMA tiles (NINT_STENCIL_AUTO).
+  // A planned launch (merged grids) has no stencil form: the caller then enqueues it by itself.
+  if (nint_internal_stencil_holds(ly) && (ly->tile_rows == 1 || (ly->tile_rows == 0 && NINT_STENCIL_AUTO(dtype)))) {
     if (plan) return NINT_E_SHAPE;
     return nint_internal_stencil_lstm(ly, g, dtype, N, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
   }
@@ -964,7 +971,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   if (pw && !pw->gates && !pw->lo_gates) return NINT_E_ARG;
   if (!dx_accum && !dh_prev && !pw) return NINT_OK;
   if (!aligned16(dG) || !aligned16(ly->Wd)) return NINT_E_ALIGN;
-  if (ly->tile_rows != 0 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
+  if (ly->tile_rows != 0 && ly->tile_rows != 1 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   const int Gc = 4 * ly->Ch16;
   ConvArgs a = {};
@@ -983,7 +990,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.out0_overwrite = overwrite_dx ? 1 : 0;
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
-  a.tile_rows = ly->tile_rows;
+  a.tile_rows = ly->tile_rows == 1 ? 0 : ly->tile_rows;    // (1 = the stencil GATE kernel: the backward launches take their own choice)
   // only the n-tiles whose destination exists are computed (fused: the Ch16 real hidden columns, not their padding)
   const int nt_x = ly->Cxp / 16, nt_h = (pw && pw->gates) ? ly->Ch16 / 16 : ly->Chp / 16;
   a.nt_begin = dx_accum ? 0 : nt_x;

@@ -15,10 +15,14 @@
 //   - weights are wave-uniform: one row of 32 f32 per (tap, channel) in iteration order (nint_pack_weights writes that
 //     image behind the MFMA images), fetched by scalar loads and fed to the FMAs as SGPR operands;
 //   - the LSTM epilogue is the one of conv_igemm.hip (same sigmoid / tanh / fmaf association), per lane, vector stores.
-// Selected by nint_cell_fwd when Ch <= 8, k = 3 and the tile height is not pinned (nint_layer.tile_rows == 0: the
-// tests run the MFMA path on the same shapes by pinning it).  BPTT of such layers stays on the MFMA kernels.
+// Run by nint_cell_fwd for nint_layer.tile_rows == 1 on layers with Ch <= 8, k = 3 and a thin input (nint_stencil_holds).
+// BPTT of such layers stays on the MFMA kernels.
 #include <type_traits>
 #include "nint_common.h"
+
+#ifndef NINT_ST_FENCE
+#define NINT_ST_FENCE 1       // scalar weight loads fenced per row pair (1) or left to the scheduler per channel quad (0)
+#endif
 
 struct StencilArgs {
   const char* xs; const char* hs;          // halo slabs (hs == nullptr: zero state, model.py:259-262)
@@ -37,37 +41,38 @@ constexpr int ST_ROWS = 8, ST_COLS = 32, ST_HW = ST_COLS + 2, ST_HH = ST_ROWS + 
 
 // rows of the stencil weight image (shared with the packer in pointwise.hip through nint_common.h)
 template <int DT>
-__global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a) {
+__global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a_) {
+  const StencilArgs& a0 = a_;
   typedef Elem<DT> E;
   constexpr int QB = 4 * E::ES;                       // bytes of a channel quad
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x;
-  const int tx = t % a.tiles_x; t /= a.tiles_x;
-  const int ty = t % a.tiles_y;
-  const int img = t / a.tiles_y;
+  const int tx = t % a0.tiles_x; t /= a0.tiles_x;
+  const int ty = t % a0.tiles_y;
+  const int img = t / a0.tiles_y;
   const int y0 = ty * ST_ROWS, x0 = tx * ST_COLS;
   // ---- stage the halo tile of both sources: [halo pixel][quads] per source, quads of the real channels only
-  const int xrow = a.xq * QB, hrow = a.hq * QB;       // LDS bytes per halo pixel
+  const int xrow = a0.xq * QB, hrow = a0.hq * QB;       // LDS bytes per halo pixel
   char* lx = smem;
   char* lh = smem + ST_HH * ST_HW * xrow;
   {
-    const char* gx = a.xs + (long)img * a.x_img + ((long)(y0 + a.P - 1) * a.Wh + (x0 + a.P - 1)) * a.x_pix;
-    const int nx = ST_HH * ST_HW * a.xq;
+    const char* gx = a0.xs + (long)img * a0.x_img + ((long)(y0 + a0.P - 1) * a0.Wh + (x0 + a0.P - 1)) * a0.x_pix;
+    const int nx = ST_HH * ST_HW * a0.xq;
     for (int u = tid; u < nx; u += 256) {
-      const int hp = u / a.xq, q = u - hp * a.xq;
+      const int hp = u / a0.xq, q = u - hp * a0.xq;
       const int hy = hp / ST_HW, hx = hp - hy * ST_HW;
-      const char* src = gx + ((long)hy * a.Wh + hx) * a.x_pix + q * QB;
+      const char* src = gx + ((long)hy * a0.Wh + hx) * a0.x_pix + q * QB;
       if constexpr (DT == NINT_BF16) *(u32x2_t*)(lx + u * QB) = *(const u32x2_t*)src;
       else *(u32x4_t*)(lx + u * QB) = *(const u32x4_t*)src;
     }
-    if (a.hs) {
-      const char* gh = a.hs + (long)img * a.h_img + ((long)(y0 + a.P - 1) * a.Wh + (x0 + a.P - 1)) * a.h_pix;
-      const int nh = ST_HH * ST_HW * a.hq;
+    if (a0.hs) {
+      const char* gh = a0.hs + (long)img * a0.h_img + ((long)(y0 + a0.P - 1) * a0.Wh + (x0 + a0.P - 1)) * a0.h_pix;
+      const int nh = ST_HH * ST_HW * a0.hq;
       for (int u = tid; u < nh; u += 256) {
-        const int hp = u / a.hq, q = u - hp * a.hq;
+        const int hp = u / a0.hq, q = u - hp * a0.hq;
         const int hy = hp / ST_HW, hx = hp - hy * ST_HW;
-        const char* src = gh + ((long)hy * a.Wh + hx) * a.h_pix + q * QB;
+        const char* src = gh + ((long)hy * a0.Wh + hx) * a0.h_pix + q * QB;
         if constexpr (DT == NINT_BF16) *(u32x2_t*)(lh + u * QB) = *(const u32x2_t*)src;
         else *(u32x4_t*)(lh + u * QB) = *(const u32x4_t*)src;
       }
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a) {
   const int py = (wave >> 1) * 4 + row, px = (wave & 1) * 16 + col;       // inside the tile
   float acc[32];
 #pragma unroll
-  for (int o = 0; o < 32; ++o) acc[o] = a.bias[(o >> 3) * 16 + (o & 7)];   // o = gate*8 + ch; bias_p is [cblock 0][gate][16]
+  for (int o = 0; o < 32; ++o) acc[o] = a0.bias[(o >> 3) * 16 + (o & 7)];   // o = gate*8 + ch; bias_p is [cblock 0][gate][16]
 
   typedef typename std::conditional<DT == NINT_BF16, u32x2_t, u32x4_t>::type quad_t;
   auto widen = [](quad_t v) __attribute__((always_inline)) {
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a) {
     else
       return __builtin_bit_cast(f32x4_t, v);
   };
-  const float* wrow = a.Ws;                           // wave-uniform: advances by 32 floats per (tap, channel)
+  const float* wrow = a0.Ws;                           // wave-uniform: advances by 32 floats per (tap, channel)
   auto fma_quad = [&](f32x4_t v) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -98,7 +103,9 @@ __global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a) {
       for (int o = 0; o < 32; ++o) acc[o] = fmaf(wrow[e * 32 + o], v[e], acc[o]);
       // (two rows = 64 scalar weights in flight; without the fence the scheduler hoists all 128 loads of the quad and
       // spills SGPRs into VGPR lanes)
+#if NINT_ST_FENCE
       if (e & 1) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     wrow += 128;
   };
@@ -118,9 +125,10 @@ __global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a) {
       if (folded) {                                   // horizontal taps live in the channels (kx*Cx + c)
         fma_quad(widen(c));
       } else {
-        quad_t el = c, er = c;                        // what the row's edge lanes need: the halo columns
-        if (col == 0) el = *(const quad_t*)(pc - rowb + q * QB);
-        if (col == 15) er = *(const quad_t*)(pc + rowb + q * QB);
+        // what the row's edge lanes need: the halo columns.  Branch-free (every lane reads; interior lanes re-read their own
+        // quad, which the shuffle overwrites): a divergent branch here makes the compiler park the weight rows in flight
+        const quad_t el = *(const quad_t*)(pc + (col == 0 ? -rowb : 0) + q * QB);
+        const quad_t er = *(const quad_t*)(pc + (col == 15 ? rowb : 0) + q * QB);
         fma_quad(widen(shuffle(c, el, false)));       // kx = 0: pixel x - 1
         fma_quad(widen(c));                           // kx = 1
         fma_quad(widen(shuffle(c, er, true)));        // kx = 2: pixel x + 1
@@ -129,12 +137,17 @@ __global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a) {
   };
 #pragma unroll 1
   for (int ky = 0; ky < 3; ++ky) {
-    source(lx, xrow, a.xq, a.xfold != 0, ky);
-    if (a.hs) source(lh, hrow, a.hq, false, ky);
-    else wrow += 3 * a.hq * 128;
+    source(lx, xrow, a0.xq, a0.xfold != 0, ky);
+    if (a0.hs) source(lh, hrow, a0.hq, false, ky);
+    else wrow += 3 * a0.hq * 128;
   }
 
-  // ---- LSTM epilogue (model.py:223-229), this lane's pixel
+  // ---- LSTM epilogue (model.py:223-229), this lane's pixel.  Its arguments are read from the kernarg segment HERE, through a
+  // pointer the compiler cannot see through: fetched at kernel entry they would sit in ~20 SGPRs across the main loop, which
+  // wants them for weight rows (SGPRs spill into VGPR lanes, one v_readlane per use).
+  const StencilArgs* kp = (const StencilArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  const StencilArgs& a = *kp;
   const int y = y0 + py, x = x0 + px;
   if (y >= a.H || x >= a.W) return;
   const size_t pix = ((size_t)img * a.H + y) * a.W + x;
@@ -179,8 +192,7 @@ __global__ __launch_bounds__(256) void stencil_lstm_kernel(StencilArgs a) {
 
 // host side -----------------------------------------------------------------------------------------------------------
 bool nint_internal_stencil_holds(const nint_layer* ly) {
-  if (!ly || ly->k != 3 || ly->Ch > 8 || ly->tile_rows != 0) return false;
-  return ly->xfold ? 3 * ly->Cx <= 64 : ly->Cx <= 16;
+  return ly && nint_stencil_shape(ly->Cx, ly->Ch, ly->k, ly->xfold);
 }
 
 extern "C" int nint_stencil_holds(const nint_layer* ly) { return nint_internal_stencil_holds(ly) ? 1 : 0; }

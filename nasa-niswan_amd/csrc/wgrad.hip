@@ -588,7 +588,7 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   const size_t i = ((size_t)(blockIdx.x - E.blk_begin) * 64 + lane) * 4;  // slab is a multiple of 1024: no tail
   f32x4_t s = {0.f, 0.f, 0.f, 0.f};
   if (grp < G) {
-#pragma unroll 4
+#pragma unroll 8
     for (int sp = grp; sp < splits; sp += G) s += *(const f32x4_t*)(part + i + (size_t)sp * slab);
   }
   red[threadIdx.x] = s;

@@ -1,8 +1,8 @@
 """The vector-ALU stencil path of the gate step (csrc/stencil.hip) -- SURVEY.md section 7 step 4 / north_star: "MFMA used only
 ... when channel count makes it a real dense contraction", reference op model.py:207-231 with ConvLSTM(4, [8], [3], 1)
-(BASELINE configs[0]).  nint_cell_fwd takes it for Ch <= 8, k = 3, thin inputs, unless the tile height is pinned -- so
-every shape here runs BOTH families: the stencil kernel (the library's choice) and the implicit-GEMM kernel
-(engine.FORCE_TILE_ROWS = 8), each against the CPU oracle (prediction, loss-weighted gradients of every parameter and of the
+(BASELINE configs[0]).  nint_cell_fwd takes it for nint_layer.tile_rows == 1 ("one pixel per lane") on layers with Ch <= 8,
+k = 3 and thin inputs -- so every shape here runs BOTH families: the stencil kernel (engine.FORCE_TILE_ROWS = 1) and the
+implicit-GEMM kernel (engine.FORCE_TILE_ROWS = 8), each against the CPU oracle (prediction, loss-weighted gradients of every parameter and of the
 input) and against each other.
 
 Tolerances: f32 outputs rtol 1e-4 / atol 1e-5 and gradients max-abs <= 1e-3 max|g| against the oracle, the two families within
@@ -73,9 +73,9 @@ def test_stencil_and_gemm_families_against_the_oracle_and_each_other(pkg, name, 
     ref = {"pred": po.detach(), "dX": Xo.grad}
     for k in params:
         ref["grad." + k] = leaf[k].grad
-    st, held = _run(pkg, params, C_, hidden, X, wgt, dtype, 0)
-    mm, held8 = _run(pkg, params, C_, hidden, X, wgt, dtype, 8)
-    assert all(held) and not any(held8), (name, held, held8)      # the library's choice is the stencil kernel; pinned rows: the GEMM
+    st, held = _run(pkg, params, C_, hidden, X, wgt, dtype, 1)
+    mm, _ = _run(pkg, params, C_, hidden, X, wgt, dtype, 8)
+    assert all(held), (name, held)                               # every layer of these stacks is a stencil shape
     for fam, res in (("stencil", st), ("gemm", mm)):
         for k, a in res.items():
             a, b = a.double(), ref[k].double()
@@ -97,11 +97,10 @@ def test_stencil_choice_is_host_arithmetic(pkg):
     from nasa_niswan_amd._lib import NintLayer
     lib = pkg.load_library()
 
-    def holds(Cx, Ch, k, xfold=0, rows=0):
+    def holds(Cx, Ch, k, xfold=0):
         ly = NintLayer()
-        ly.Cx, ly.Ch, ly.k, ly.xfold, ly.tile_rows = Cx, Ch, k, xfold, rows
+        ly.Cx, ly.Ch, ly.k, ly.xfold = Cx, Ch, k, xfold
         return bool(lib.nint_stencil_holds(C.byref(ly)))
 
     assert holds(4, 8, 3, 1) and holds(8, 8, 3, 0) and holds(16, 4, 3, 0) and holds(21, 8, 3, 1)
-    assert not holds(4, 8, 3, 1, rows=8)          # pinned tile height: the implicit-GEMM kernel
     assert not holds(4, 16, 3, 1) and not holds(4, 8, 5, 1) and not holds(17, 8, 3, 0) and not holds(22, 8, 3, 1)
