@@ -165,6 +165,7 @@ def parse_args(argv=None):
     ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 1, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape; 1 = the stencil gate kernel where it holds)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--phase-events", type=int, default=0, help="after the timed region, bracket the phases of this many more steps with HIP events (phase_ms in the line: pack+forward, head/loss, BPTT+weight gradients, all-reduce+Adam)")
     ap.add_argument("--lib", default=None, help="load this build of the library (A/B copies made by nasa-niswan_amd/build.py --out=...) instead of the product one")
     return ap.parse_args(argv)
 
@@ -340,6 +341,22 @@ def main():
         # ring all-reduce: every rank sends and receives 2 (N-1)/N of the bucket; "bus bandwidth" as nccl-tests define it
         bus_bw = (2.0 * (world - 1) / world) * nbytes / (ar_ms * 1e-3) / 1e9 if world > 1 else None
 
+    # ---- phase split of the step by HIP events (diagnostic: which phase a slow process loses its time in)
+    phase_ms = None
+    if args.phase_events > 0:
+        import numpy as _np
+        rows = []
+        for _ in range(args.phase_events):
+            trainer._marks = []
+            trainer.step(X, y)
+            torch.cuda.synchronize()
+            ev = trainer._marks
+            rows.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+        trainer._marks = None
+        med = _np.median(_np.array(rows), axis=0)
+        phase_ms = {"pack_forward": round(float(med[0]), 4), "head_loss": round(float(med[1]), 4), "bptt_wgrad_fold": round(float(med[2]), 4),
+                    "allreduce_adam": round(float(med[3]), 4), "steps": args.phase_events}
+
     # ---- per-rank step time (N > 1): the slowest rank sets `value`; the spread says whether one device lags
     rank_ms = None
     if use_dist:
@@ -460,7 +477,7 @@ def main():
         wg_loop = time_kernel(k_wgrad, 10, st)
         roof_all = [
             dict(roof, launches_per_step=T - 1 if us_gate is not None else T),
-            dict(entry("wgrad_layer0", "wgrad_kernel layer 0: x part over T steps + h part over T-1 steps (in the step, without the fold launch)",
+            dict(entry("wgrad_layer0", "layer-0 weight gradient (bf16: wgrad_wide_kernel<5, 2>, the 8-wave 128-column kernel; f32: wgrad_kernel): x part over T steps + h part over T-1 steps (in the step, without the fold launch)",
                        "mfma", f_wgrad, ms_(us_wg), wg_loop * f_wgrad / f_wgrad_loop,
                        note=f"loop figure = the stand-alone entry (all T steps of both sources + the fold, {wg_loop:.3f} ms) scaled by the executed / nominal FLOPs"),
                  launches_per_step=1),
@@ -521,6 +538,7 @@ def main():
             "allreduce_bytes": trainer.flat.grad.numel() * 4 if use_dist else None,
             "bus_bw_GBs": None if bus_bw is None else round(bus_bw, 2),
             "bus_bw_bound_GBs": XGMI_LINK_GBS if world > 1 else None,
+            "phase_ms": phase_ms,
             "roofline": roof,
             "roofline_kernels": roof_all,
             "phases": phases,

@@ -21,7 +21,7 @@
 #include "nint_common.h"
 
 #ifndef NINT_ST_FENCE
-#define NINT_ST_FENCE 1       // scalar weight loads fenced per row pair (1) or left to the scheduler per channel quad (0)
+#define NINT_ST_FENCE 0       // scalar weight loads fenced per row pair (1: 52 us on the full grid, bf16) or left to the scheduler per channel quad (0: 44 us)
 #endif
 
 struct StencilArgs {

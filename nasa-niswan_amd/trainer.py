@@ -40,6 +40,7 @@ class FusedTrainer:
         self.stats = torch.zeros(NINT_LOSS_STATS, dtype=torch.float64, device=dev)
         self._dpred = None
         self._probe = (None, 0)
+        self._marks = None      # diagnostic: a list that step() fills with HIP events (start, after forward, after head/loss, after BPTT, end)
         import torch.distributed as dist
         self.dist = dist
         self.pg = process_group
@@ -98,8 +99,11 @@ class FusedTrainer:
         pb, pm = self._probe
         ws.seq.probe = pb.data_ptr() if pb is not None else None
         ws.seq.probe_mask, ws.seq.probe_slots = pm, (pb.numel() // 2 if pb is not None else 0)
+        mark = self._mark
+        mark()
         eng.pack_weights([c.conv.weight for c in m.layers], [c.conv.bias for c in m.layers])
         eng.forward(ws, X)
+        mark()
         O = m.conv.weight.shape[0]
         Hc, Wc = y.shape[-2], y.shape[-1]
         yv = y.detach().float().contiguous()
@@ -115,12 +119,22 @@ class FusedTrainer:
                                                  B, O, H, W, self.halo[0], self.halo[1], Hc, Wc, stream_ptr()),
                   "nint_loss_mse_l1_crop")
         eng.head_backward(ws, m.conv.weight, dpred, dw_out=self._dw_head, db_out=self._db_head, write_dh=not fused)
+        mark()
         eng.backward(ws, False, zero_state_grads=range(L), dW_out=self._dW, db_out=self._db)
+        mark()
         eng.release(ws)
         if self.distributed:
             self.dist.all_reduce(self.flat.grad, op=self.dist.ReduceOp.SUM, group=self.pg)   # RCCL over xGMI
         self.optimizer.step(grad_scale=1.0 / self.world)
+        mark()
         return self.scratch[0]
+
+    def _mark(self):
+        """bench.py --phase-events: one HIP event per phase boundary of a step (nothing is recorded unless asked for)"""
+        if self._marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self._marks.append(ev)
 
     @torch.no_grad()
     def evaluate(self, X: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

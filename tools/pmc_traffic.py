@@ -9,7 +9,7 @@ import sys
 KEYS = {   # kernel-name prefix in the summary -> (bench key, launches of that kernel per priced "launch")
     "void conv_igemm_kernel<1, 0, 4, 1, 4, 8>": ("conv_igemm_fwd_layer0", 1),
     "void conv_igemm_kernel<1, 1, 1, 4, 4, 8>": ("conv_igemm_dgrad_layer0", 1),
-    "void wgrad_kernel<1, 7, 1, 5, 1, 5>": ("wgrad_layer0", 2),          # x part + h part
+    "void wgrad_wide_kernel<5, 2>": ("wgrad_layer0", 2),                 # x part + h part (round 4: the 8-wave 128-column kernel)
     "void lstm_bwd_pointwise_kernel<1>": ("lstm_bwd_pointwise_layer0", 1),
 }
 txt = open(sys.argv[1]).read()
