@@ -127,8 +127,6 @@ struct ConvArgs {
   int nhp_pad2;                         // halo-tile pixels of a merged tile (MT/2 rows x 32 pixels), rounded up to 16
   unsigned magic_nhpp2, magic_hwt2;
   int tile_rows;         // 0 = per launch shape, 4 / 8 = forced tile height
-  int ntl, tpw;          // tiles of the launch (full + merged); consecutive tiles per workgroup (1, or several: the next tile's
-                         // halo image is requested under this tile's epilogue)
   int cpf;               // channel chunks per LDS A fill
   int a_bytes;           // bytes reserved for the A image
   int nhp_pad;           // halo-tile pixels rounded up to 16 (one g-plane of the A image)

@@ -29,6 +29,9 @@ enum { EPI_LSTM = 0, EPI_DGRAD = 1, EPI_DGRAD_PW = 2 };
 
 // The library's own choice between the stencil kernel and the padded MFMA tiles for layers both hold (tile_rows == 0).
 // Measured on the full 100 x 154 grid, B = 8, configs[0]'s layer (4 -> 8, 3x3): see DESIGN.md section 6.
+#ifndef NINT_TPW_MAX
+#define NINT_TPW_MAX 4          // consecutive tiles per persistent workgroup, at most (1 = a workgroup per tile, as before round 4)
+#endif
 #ifndef NINT_STENCIL_AUTO
 #define NINT_STENCIL_AUTO(dtype) false
 #endif
@@ -118,46 +121,99 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, c
   constexpr int Q = MT / WK;       // rows whose epilogue this wave runs (K-slice waves split the rows)
   static_assert(MT % WK == 0, "K-slice waves split the tile rows evenly");
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   NINT_STAMP_AT(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wk = wave / WN;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
   // with its own L2, so XCD x takes the CONTIGUOUS tile range x: neighbouring tiles (which share halo
   // pixels) and, at B = 8, whole images then stay inside one L2.  Any bijection is correct.
-  int tile;
+  int grp;
   {
     const int nb = nbx_, b = bx_, q8 = nb / 8, r8 = nb % 8, x = b % 8, i = b / 8;
-    tile = x * q8 + (x < r8 ? x : r8) + i;     // ranges of q8 (+1 for the first r8 XCDs) tiles
+    grp = x * q8 + (x < r8 ? x : r8) + i;      // ranges of q8 (+1 for the first r8 XCDs) tile groups
   }
   // Two tile classes.  FULL tiles: MT rows x 16 pixels.  When the grid leaves 1..MT/2 rows over (100 = 12*8 + 4), the
   // leftover strip is covered by MERGED tiles: MT/2 rows x 32 pixels, i.e. the MT row tiles of a workgroup are the
   // rows of two adjacent 16-pixel columns.  No row tile computes padding rows, and at B = 8 the bench's gate launch
-  // is 8 * (12*10 + 5) = 1000 workgroups instead of 1040: they fit the chip's 512 slots in two rounds, without the
-  // 16-workgroup third round that kept 15 of 16 CUs idle for the last 30 us (tools/clockprobe.py).
-  const bool mg = MT >= 8 && tile >= a.n_full;                 // workgroup-uniform
-  int tx, ty, img;
-  if (!mg) {
-    tx = tile % a.tiles_x; tile /= a.tiles_x;
-    ty = tile % a.tiles_full_y;
-    img = tile / a.tiles_full_y;
-  } else {
-    tile -= a.n_full;
-    tx = tile % a.tiles_x2;
-    img = tile / a.tiles_x2;
-    ty = a.tiles_full_y;
-  }
+  // is 8 * (12*10 + 5) = 1000 tiles instead of 1040.
   constexpr int RHM = MT >= 8 ? MT / 2 : MT;                   // rows of a merged tile
   const int nt0 = a.nt_begin + by_ * NTWG + wn * NTW;   // first n-tile of this wave
-  const int y0 = ty * MT, x0 = mg ? tx * 32 : tx * 16;
+  const int p = a.p, k = a.k, taps = a.taps;
+  const int nchunks = a.nchunk0 + a.nchunk1;
+  struct TileGeo { bool mg; int img, y0, x0, HWt, NHP, NHPp; unsigned magic_nhpp, magic_hwt; const char* base0; const char* base1; };
+  auto geo = [&](int tile) __attribute__((always_inline)) {
+    TileGeo G;
+    G.mg = MT >= 8 && tile >= a.n_full;                        // workgroup-uniform
+    int tx, ty;
+    if (!G.mg) {
+      tx = tile % a.tiles_x; tile /= a.tiles_x;
+      ty = tile % a.tiles_full_y;
+      G.img = tile / a.tiles_full_y;
+    } else {
+      tile -= a.n_full;
+      tx = tile % a.tiles_x2;
+      G.img = tile / a.tiles_x2;
+      ty = a.tiles_full_y;
+    }
+    G.y0 = ty * MT; G.x0 = G.mg ? tx * 32 : tx * 16;
+    G.HWt = (G.mg ? 32 : 16) + 2 * p;                          // halo tile width
+    G.NHP = ((G.mg ? RHM : MT) + 2 * p) * G.HWt;               // halo tile pixels
+    G.NHPp = G.mg ? a.nhp_pad2 : a.nhp_pad;                    // padded to a multiple of 16 pixels (planes stay bank aligned)
+    G.magic_nhpp = G.mg ? a.magic_nhpp2 : a.magic_nhpp; G.magic_hwt = G.mg ? a.magic_hwt2 : a.magic_hwt;
+    G.base0 = a.src0 + (long)G.img * a.img_stride0 + ((long)(G.y0 + a.P - p) * a.Wh + (G.x0 + a.P - p)) * a.pix_stride0;
+    G.base1 = a.src1 ? a.src1 + (long)G.img * a.img_stride1 + ((long)(G.y0 + a.P - p) * a.Wh + (G.x0 + a.P - p)) * a.pix_stride1
+                     : nullptr;
+    return G;
+  };
+  // ---- stage the halo tile of tile G for chunks [c_begin, c_begin + cpf): global -> LDS ----
+  // LDS-DMA fill: one global_load_lds_dwordx4 per wave moves 64 consecutive 16-byte units of the image
+  // (wave-uniform LDS base + lane*16; the SOURCE address is per lane), no VGPR round trip, so the whole
+  // image is in flight at once instead of FB loads per thread.  Units of the pad pixels re-read pixel 0
+  // (their LDS slots are never used); a_units is a multiple of 64.  The next workgroup barrier drains the DMA.
+  auto fill = [&](const TileGeo& G, int c_begin) __attribute__((always_inline)) {
+    const int c_cnt = min(a.cpf, nchunks - c_begin);
+    const int a_units = c_cnt * 4 * G.NHPp;
+    for (int ub = wave * 64; ub < a_units; ub += 4 * 64) {
+      const int u = ub + lane0;
+      // u / NHPp and hp / HWt by multiply-high with host-side magic numbers (exact for u < 65536, divisor <= 4096):
+      // an integer division by a run-time value costs ~25 VALU instructions, and there are two per unit
+      const int cq = (int)__umulhi((unsigned)u, G.magic_nhpp);   // cl*4 + q
+      int hp = u - cq * G.NHPp;
+      hp = hp < G.NHP ? hp : 0;
+      const int q = cq & 3, cl = cq >> 2;
+      const int hy = (int)__umulhi((unsigned)hp, G.magic_hwt);
+      const int hx = hp - hy * G.HWt;
+      const int c = c_begin + cl;
+      const char* src = (c < a.nchunk0)
+          ? G.base0 + ((long)hy * a.Wh + hx) * a.pix_stride0 + c * 64 + q * 16
+          : G.base1 + ((long)hy * a.Wh + hx) * a.pix_stride1 + (c - a.nchunk0) * 64 + q * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + (size_t)ub * 16), 16, 0, 0);
+    // (default cache policy: neighbouring tiles re-read the halo pixels; a non-temporal fill measured -8 % on the step)
+    }
+  };
+  // A workgroup owns a.tpw CONSECUTIVE tiles (1: the launch has a workgroup per tile).  With several, the halo image of
+  // the next tile is requested as soon as this tile's image is dead -- after the K loop and the K-slice exchange, behind a
+  // barrier -- so the fill (an L2 -> LDS burst at the LDS-DMA rate, ~25 GB/s per CU) lands under this tile's epilogue (an
+  // HBM burst of its own) instead of in front of the next K loop; and the launch is one round of resident workgroups
+  // instead of two rounds with a dispatch seam between them.
+  const int tile_first = grp * a.tpw, tile_end = min(a.ntl, tile_first + a.tpw);
+  TileGeo Gn = {};
+  bool pre = false;                            // Gn's first fill is already in flight
+  for (int tile = tile_first; tile < tile_end; ++tile) {
+  // (an opaque copy of the lane id per tile: everything below that is derived from it -- fragment offsets, epilogue
+  // addresses -- is then recomputed per tile instead of hoisted out of the tile loop and kept in registers across the K loop,
+  // which cost the 4-row kernels their fourth workgroup per CU)
+  int lane = lane0;
+  asm volatile("" : "+v"(lane));
+  const TileGeo G = pre ? Gn : geo(tile);
+  const bool mg = G.mg;
+  const int img = G.img, y0 = G.y0, x0 = G.x0, HWt = G.HWt, NHP = G.NHP, NHPp = G.NHPp;
+  const char* const base0 = G.base0; const char* const base1 = G.base1;
   // row tile r of the workgroup sits at (y0 + rdy(r), x0 + rdx(r))
   auto rdy = [&](int r) __attribute__((always_inline)) { return mg ? r % RHM : r; };
   auto rdx = [&](int r) __attribute__((always_inline)) { return mg ? 16 * (r / RHM) : 0; };
-  const int p = a.p, k = a.k, taps = a.taps;
-  const int HWt = (mg ? 32 : 16) + 2 * p;      // halo tile width
-  const int NHP = ((mg ? RHM : MT) + 2 * p) * HWt;   // halo tile pixels
-  const int NHPp = mg ? a.nhp_pad2 : a.nhp_pad;      // padded to a multiple of 16 pixels (planes stay bank aligned)
-  const unsigned magic_nhpp = mg ? a.magic_nhpp2 : a.magic_nhpp, magic_hwt = mg ? a.magic_hwt2 : a.magic_hwt;
   const int plane = NHPp * 16;                 // bytes of one g-plane
   const int chunk_bytes = 4 * plane;
 
@@ -174,12 +230,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, c
     for (int i = 0; i < MT; ++i) acc[i][j] = b0;
   }
 
-  const int nchunks = a.nchunk0 + a.nchunk1;
-  const char* base0 = a.src0 + (long)img * a.img_stride0 +
-                      ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.pix_stride0;
-  const char* base1 = a.src1 ? a.src1 + (long)img * a.img_stride1 +
-                                   ((long)(y0 + a.P - p) * a.Wh + (x0 + a.P - p)) * a.pix_stride1
-                             : nullptr;
   const int a_lane_off = (lane >> 4) * plane + (lane & 15) * 16;
   // local accumulator row i of K-slice wk is tile row (i + wk*Q) % MT: the rows a wave owns after the
   // K-slice exchange are then always its local rows 0..Q-1 (static register indexing)
@@ -242,30 +292,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, c
   for (int c_begin = 0; c_begin < nchunks; c_begin += a.cpf) {
     const int c_cnt = min(a.cpf, nchunks - c_begin);
     if (c_begin > 0) __syncthreads();          // every wave is done reading the previous image
-    // ---- stage the halo tile for chunks [c_begin, c_begin+c_cnt): global -> LDS ----
-    const int a_units = c_cnt * 4 * NHPp;
-    // LDS-DMA fill: one global_load_lds_dwordx4 per wave moves 64 consecutive 16-byte units of the image
-    // (wave-uniform LDS base + lane*16; the SOURCE address is per lane), no VGPR round trip, so the whole
-    // image is in flight at once instead of FB loads per thread.  Units of the pad pixels re-read pixel 0
-    // (their LDS slots are never used); a_units is a multiple of 64.  The barrier below drains the DMA.
-    for (int ub = wave * 64; ub < a_units; ub += 4 * 64) {
-      const int u = ub + lane;
-      // u / NHPp and hp / HWt by multiply-high with host-side magic numbers (exact for u < 65536, divisor <= 4096):
-      // an integer division by a run-time value costs ~25 VALU instructions, and there are two per unit
-      const int cq = (int)__umulhi((unsigned)u, magic_nhpp);   // cl*4 + q
-      int hp = u - cq * NHPp;
-      hp = hp < NHP ? hp : 0;
-      const int q = cq & 3, cl = cq >> 2;
-      const int hy = (int)__umulhi((unsigned)hp, magic_hwt);
-      const int hx = hp - hy * HWt;
-      const int c = c_begin + cl;
-      const char* src = (c < a.nchunk0)
-          ? base0 + ((long)hy * a.Wh + hx) * a.pix_stride0 + c * 64 + q * 16
-          : base1 + ((long)hy * a.Wh + hx) * a.pix_stride1 + (c - a.nchunk0) * 64 + q * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + (size_t)ub * 16), 16, 0, 0);
-    // (default cache policy: neighbouring tiles re-read the halo pixels; a non-temporal fill measured -8 % on the step)
-    }
+    if (!(c_begin == 0 && pre)) fill(G, c_begin);   // (the first fill of a tile after the workgroup's first: requested under the previous epilogue)
     // K-steps of this fill in two SEGMENTS: chunks of a horizontally folded source 0 (nint_layer.xfold: channel =
     // (kx, c), so only the k vertical taps of the halo tile's centre column remain: kx0 = 1) and all other chunks
     // (k x k taps).  Without folding segment 0 is empty and everything below is the one-segment loop.
@@ -457,6 +484,27 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, c
   // row wait for the previous row's stores to be acknowledged (measured: 22 us of epilogue per round).
   if constexpr (!EARLY) load_cprev();
   load_old();
+  pre = tile + 1 < tile_end;
+  if (pre) {
+    // The image (and the exchange buffer over it) is dead once every wave is past its last LDS read: barrier, then the
+    // next tile's first fill.  vmcnt retires in order, so this tile's epilogue operands are made to ARRIVE first (the
+    // empty asm uses them: the compiler puts its wait here, ahead of the DMA, not behind it).
+    Gn = geo(tile + 1);
+    if constexpr (EPI == EPI_LSTM && !EARLY) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i)
+#pragma unroll
+        for (int cb = 0; cb < NTW / 4; ++cb) asm volatile("" : "+v"(cpv[i][cb]));
+    }
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(old[i][j]));
+    }
+    __syncthreads();
+    fill(Gn, 0);
+  }
   const int px = lane & 15;
   const int c4 = 4 * (lane >> 4);
   const int x = x0 + px;
@@ -670,6 +718,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, c
       }
     }
   }
+  }   // tile
   NINT_STAMP_AT(3)
 }
 
@@ -803,15 +852,33 @@ static int launch_cfg(ConvArgs& a, int N, int ngroups_y, hipStream_t st, ConvPla
   size_t lds = (size_t)a.a_bytes;
   if ((size_t)red_bytes > lds) lds = red_bytes;
   if (lds > 160 * 1024) return NINT_E_LDS;
+  a.ntl = a.n_full + N * a.tiles_x2;
+  a.tpw = 1;
   if (plan) {
-    plan->a = a; plan->gx = a.n_full + N * a.tiles_x2; plan->gy = ngroups_y; plan->lds = lds;
+    plan->a = a; plan->gx = a.ntl; plan->gy = ngroups_y; plan->lds = lds;
     plan->variant = conv_variant(EPI, WN, WK, NTW, MT);
     return NINT_OK;
+  }
+  // Launches of more than one round of resident workgroups give every workgroup as many consecutive tiles as there are
+  // rounds (at most NINT_TPW_MAX): the workgroup requests tile i+1's halo image under tile i's epilogue (conv_igemm_body).
+  // Residency: the kernel's launch bounds (2 workgroups per CU for 8-row tiles, 3 or 4 for 4-row tiles), capped by LDS.
+  {
+    int n_cu = 256;
+    { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
+    constexpr int occ_regs = MT >= 8 ? 2 : (xchg_rounds(EPI, WK, NTW, MT) == 2 && DT == NINT_BF16 && EPI != EPI_DGRAD_PW ? 4 : 3);
+    int occ = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    if (occ > occ_regs) occ = occ_regs;
+    if (occ < 1) occ = 1;
+    const long slots = (long)n_cu * occ, wgs = (long)a.ntl * ngroups_y;
+    int tpw = (int)((wgs + slots - 1) / slots);
+    if (tpw > NINT_TPW_MAX) tpw = NINT_TPW_MAX;
+    if (tpw < 1 || a.tile_rows != 0) tpw = 1;             // (a pinned tile height pins the launch shape: one tile per workgroup)
+    a.tpw = tpw;
   }
   auto kern = conv_igemm_kernel<DT, EPI, WN, WK, NTW, MT>;
   if (lds > 64 * 1024)
     NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid(a.n_full + N * a.tiles_x2, ngroups_y), block(256);
+  dim3 grid(nint_cdiv(a.ntl, a.tpw), ngroups_y), block(256);
   hipLaunchKernelGGL(kern, grid, block, lds, st, a);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
