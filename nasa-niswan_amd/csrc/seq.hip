@@ -251,7 +251,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // ADJACENT launches that share no buffer when the stack has three or more layers (the top layer's step touches its own
   // state and layer L-2's; the bottom dgrad reads dG[0] and writes dh[0] / dx): they go out as ONE grid
   // (nint_internal_conv_multi).  The bottom dgrad is held back (`pend`) until the next launch is known.
-  const bool merge = s->wave && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];
+  const bool merge = s->wave == 1 && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];   // (wave == 2: the forward wavefront only)
   struct { bool on; ConvPlan plan; const void* dG; void* dx; void* dh_prev; bool ow; } pend = {};
   auto flush = [&]() {                           // the held-back dgrad as a launch of its own
     if (!pend.on) return (int)NINT_OK;

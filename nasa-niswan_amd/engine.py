@@ -23,8 +23,9 @@ XFOLD = True
 # nint_layer.wide of engines built afterwards (weight-gradient kernel family): 0 = the library's choice, 1 = always the 4-wave
 # 64-column kernel, 2 = the 8-wave 128-column kernel wherever it is instantiated (tests run both against each other)
 FORCE_WIDE = 0
-FORCE_WAVE = None        # forward (t, layer) wavefront as one grid per step: None = by batch size (SeqEngine._set_wave), 0 = never, 1 = always
-WAVE_TILES_PER_CU = 5     # ... on while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs
+FORCE_WAVE = None        # merged grids (nint_seq.wave): None = by batch size (SeqEngine._set_wave), 0 = never, 1 = forward wavefront + backward pair, 2 = forward wavefront only
+WAVE_TILES_PER_CU = 5     # ... both on while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs
+WAVE_FWD_TILES_PER_CU = 9 # ... the forward wavefront alone up to this (B = 8 at 100 x 154: 1000 tiles on 256 CUs)
 FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
 
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
@@ -253,8 +254,14 @@ class SeqEngine:
         step) as one grid.  FORCE_WAVE = None: on for the strong-scaling shapes (up to ~2.5 eight-row pixel tiles per CU:
         B <= 5 per GPU at 100 x 154; measured +10 / +7 / +2 % at B = 1 / 2 / 4, bimodal at B = 8), 0 / 1: off / on."""
         tiles8 = ws.B * ((ws.W + 15) // 16) * ((ws.H + 7) // 8)
-        on = (2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu) if FORCE_WAVE is None else bool(FORCE_WAVE)
-        ws.seq.wave = int(on and len(self.cfgs) > 1)
+        if FORCE_WAVE is None:
+            # round 4, six fresh processes per setting at B = 8 (profiles/r04_c_wave_repeats.txt): the forward wavefront as one
+            # grid per step is 2.79-2.83 ms of forward against 2.87-2.94 in every process but one; the backward pair is neutral
+            # (4.82-4.93 against 4.84-4.92 ms) with one slow process in six (5.01): that pair was the "bimodal" of round 3
+            mode = 1 if 2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu else (2 if 2 * tiles8 < WAVE_FWD_TILES_PER_CU * self.n_cu else 0)
+        else:
+            mode = int(FORCE_WAVE)
+        ws.seq.wave = mode if len(self.cfgs) > 1 else 0
 
     def pack_input(self, ws: Workspace, x):
         """Fill the input slab ws.xs (image t*B+b, channels-last ET, folded for thin inputs) from x: a (B,T,C,H,W)

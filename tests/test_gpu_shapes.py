@@ -226,8 +226,9 @@ def test_forward_wavefront_as_one_grid_per_step_changes_no_bit(pkg, shape, dtype
 
 
 def test_forward_wavefront_rule_and_fallback(pkg):
-    """The engine's own rule (FORCE_WAVE None) turns the merged grids on for B = 1 and B = 4 at the bench grid (B = 4: the
-    first layer on 8-row tiles, the *_multi8 kernels) and off for B = 8; forced on / off the results are the same bit for bit."""
+    """The engine's own rule (FORCE_WAVE None) turns both merged grids on for B = 1 and B = 4 at the bench grid (B = 4: the
+    first layer on 8-row tiles, the *_multi8 kernels) and the forward wavefront alone for B = 8 (nint_seq.wave = 2: round 4);
+    forced on / off the results are the same bit for bit."""
     from nasa_niswan_amd import engine
     assert engine.FORCE_WAVE is None
     torch.manual_seed(5)
@@ -235,7 +236,7 @@ def test_forward_wavefront_rule_and_fallback(pkg):
     X1, X4, X8 = (torch.randn(b, 2, 62, 100, 154, device="cuda") for b in (1, 4, 8))
     with torch.no_grad():
         p1, p4, p8 = net(X1), net(X4), net(X8)
-    assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 1, 4: 1, 8: 0}
+    assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 1, 4: 1, 8: 2}
     engine.FORCE_WAVE = 1
     try:
         with torch.no_grad():
@@ -246,7 +247,7 @@ def test_forward_wavefront_rule_and_fallback(pkg):
     engine.FORCE_WAVE = 0
     try:
         with torch.no_grad():
-            q1, q4 = net(X1), net(X4)
+            q1, q4, r8 = net(X1), net(X4), net(X8)
     finally:
         engine.FORCE_WAVE = None
-    assert torch.equal(p1, q1) and torch.equal(p4, q4)
+    assert torch.equal(p1, q1) and torch.equal(p4, q4) and torch.equal(p8, r8)
