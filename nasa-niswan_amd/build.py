@@ -21,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnint_hip.so")
-SOURCES = ["conv_igemm.hip", "stencil.hip", "wgrad.hip", "pointwise.hip", "seq.hip"]
+SOURCES = ["conv_igemm.hip", "stencil.hip", "tiny_gemm.hip", "wgrad.hip", "pointwise.hip", "seq.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wall", "-Wno-unused-variable", "-Wno-unused-local-typedef"]

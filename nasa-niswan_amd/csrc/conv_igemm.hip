@@ -29,6 +29,9 @@ enum { EPI_LSTM = 0, EPI_DGRAD = 1, EPI_DGRAD_PW = 2 };
 
 // The library's own choice between the stencil kernel and the padded MFMA tiles for layers both hold (tile_rows == 0).
 // Measured on the full 100 x 154 grid, B = 8, configs[0]'s layer (4 -> 8, 3x3): see DESIGN.md section 6.
+#ifndef NINT_TINY_AUTO
+#define NINT_TINY_AUTO true
+#endif
 #ifndef NINT_STENCIL_AUTO
 #define NINT_STENCIL_AUTO(dtype) false
 #endif
@@ -726,6 +729,8 @@ __global__ __launch_bounds__(256, 2) void conv_lstm_multi8_kernel(ConvMulti m) {
   NINT_MULTI_PROLOGUE
   switch (m.variant[i]) {
     NINT_MULTI_CASE8(EPI_LSTM, 4, 1, 4)
+    NINT_MULTI_CASE8(EPI_LSTM, 2, 2, 4)
+    NINT_MULTI_CASE8(EPI_LSTM, 1, 4, 4)
     NINT_MULTI_CASE(EPI_LSTM, 4, 1, 4)
     NINT_MULTI_CASE(EPI_LSTM, 2, 2, 4)
     NINT_MULTI_CASE(EPI_LSTM, 1, 4, 4)
@@ -756,6 +761,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_multi8_kernel(ConvMulti m) {
 static bool multi_holds(int variant) {
   switch (variant) {
     case conv_variant(EPI_LSTM, 4, 1, 4, 8): case conv_variant(EPI_DGRAD, 1, 4, 4, 8):      // (the *_multi8 kernels)
+    case conv_variant(EPI_LSTM, 2, 2, 4, 8): case conv_variant(EPI_LSTM, 1, 4, 4, 8):
     case conv_variant(EPI_LSTM, 4, 1, 4, 4): case conv_variant(EPI_LSTM, 2, 2, 4, 4): case conv_variant(EPI_LSTM, 1, 4, 4, 4):
     case conv_variant(EPI_DGRAD, 1, 4, 4, 4): case conv_variant(EPI_DGRAD, 1, 4, 2, 4): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 4):
       return true;
@@ -904,6 +910,11 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
   if (nint_internal_stencil_holds(ly) && (ly->tile_rows == 1 || (ly->tile_rows == 0 && NINT_STENCIL_AUTO(dtype)))) {
     if (plan) return NINT_E_SHAPE;
     return nint_internal_stencil_lstm(ly, g, dtype, N, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
+  }
+  // ... and the library's own choice for such layers: the matrix pipe with a DENSE K (csrc/tiny_gemm.hip)
+  if (ly->tile_rows == 0 && NINT_TINY_AUTO && nint_tiny_shape(ly->Cx, ly->Ch, ly->k, ly->xfold, dtype)) {
+    if (plan) return NINT_E_SHAPE;
+    return nint_internal_tiny_lstm(ly, g, dtype, N, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
   }
   return dtype == NINT_BF16 ? launch_conv<NINT_BF16, EPI_LSTM>(a, N, a.NTt, st, plan)
                             : launch_conv<NINT_F32, EPI_LSTM>(a, N, a.NTt, st, plan);

@@ -187,6 +187,25 @@ __host__ __device__ inline size_t nint_internal_stencil_offset(int Cxp, int Chp,
   const size_t img = (size_t)(Cxp + Chp) * 4 * Ch16 * k * k * (dtype == NINT_BF16 ? 2 : 4);    // both MFMA images fit in this
   return (img + 255) / 256 * 256;
 }
+// tiny_gemm.hip: the same layers on the matrix pipe with a DENSE K: K is a list of 16-byte groups (8 bf16 / 4 f32 channels of one
+// halo pixel of one source), four groups per K-step.  Group order: the x source's groups (folded: per vertical tap the centre
+// pixel's xg groups; plain: per tap (ky, kx) the pixel's xg groups), then the h source's (per tap, hg groups).
+constexpr int NINT_TINY_MAXSTEPS = 12, NINT_TINY_HW = 34;      // K-steps a wave keeps in registers; halo tile width (32 + 2)
+__host__ __device__ inline int nint_tiny_xg(int Cx, int xfold, int dtype) { return nint_cdiv((xfold ? 3 * Cx : Cx) * (dtype == NINT_BF16 ? 2 : 4), 16); }
+__host__ __device__ inline int nint_tiny_hg(int Ch, int dtype) { return nint_cdiv(Ch * (dtype == NINT_BF16 ? 2 : 4), 16); }
+__host__ __device__ inline int nint_tiny_ngx(int Cx, int xfold, int dtype) { return (xfold ? 3 : 9) * nint_tiny_xg(Cx, xfold, dtype); }
+__host__ __device__ inline bool nint_tiny_shape(int Cx, int Ch, int k, int xfold, int dtype) {
+  return nint_stencil_shape(Cx, Ch, k, xfold) &&
+         nint_cdiv(nint_tiny_ngx(Cx, xfold, dtype) + 9 * nint_tiny_hg(Ch, dtype), 4) <= NINT_TINY_MAXSTEPS;
+}
+__host__ __device__ inline size_t nint_tiny_bytes() { return (size_t)NINT_TINY_MAXSTEPS * 2 * 1024 + 4 * NINT_TINY_MAXSTEPS * sizeof(int) + 64; }
+__host__ __device__ inline size_t nint_internal_tiny_offset(int Cx, int Cxp, int Ch, int Chp, int Ch16, int k, int xfold, int dtype) {
+  const size_t o = nint_internal_stencil_offset(Cxp, Chp, Ch16, k, dtype) + ((size_t)3 * nint_stencil_rows(Cx, Ch, xfold) + 1) * 128;
+  return (o + 255) / 256 * 256;
+}
+int nint_internal_tiny_lstm(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* x_slab,
+                            const void* h_prev, const float* c_prev, void* h_out, float* c_out, void* gates_out,
+                            void* stream);
 bool nint_internal_stencil_holds(const nint_layer* ly);
 int nint_internal_stencil_lstm(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* x_slab,
                                const void* h_prev, const float* c_prev, void* h_out, float* c_out, void* gates_out,

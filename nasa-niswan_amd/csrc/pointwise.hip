@@ -322,8 +322,60 @@ __device__ __forceinline__ void pack_weights_body(const float* __restrict__ W, c
   const int rpk = st ? nint_stencil_rows(Cx, Ch, xfold) : 0;
   const size_t ns = (size_t)3 * rpk * 32;
   float* Ws = (float*)((char*)Wf + nint_internal_stencil_offset(Cxp, Chp, Ch16, k, DT));
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nf + nd + nb + ns; i += (size_t)gridDim.x * blockDim.x) {
-    if (i >= nf + nd + nb) {
+  // dense-K image (csrc/tiny_gemm.hip): [K-step][column tile 2][lane 64][16 B] in ET + the group table (ints) behind it
+  const bool tg = nint_tiny_shape(Cx, Ch, k, xfold, DT);
+  const size_t ntg = tg ? (size_t)NINT_TINY_MAXSTEPS * 2 * 64 * E::EPL : 0;
+  const size_t ntt = tg ? 4 * NINT_TINY_MAXSTEPS : 0;
+  char* Wt = (char*)Wf + nint_internal_tiny_offset(Cx, Cxp, Ch, Chp, Ch16, k, xfold, DT);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nf + nd + nb + ns + ntg + ntt; i += (size_t)gridDim.x * blockDim.x) {
+    if (i >= nf + nd + nb + ns) {
+      const size_t ii = i - nf - nd - nb - ns;
+      const int xg = nint_tiny_xg(Cx, xfold, DT), hg = nint_tiny_hg(Ch, DT), ngx = nint_tiny_ngx(Cx, xfold, DT), ng = ngx + 9 * hg;
+      // group gi -> (source, tap, 16-byte piece q of the pixel)
+      auto group = [&](int gi, int& ky, int& kx, int& q, bool& isx) {
+        isx = gi < ngx;
+        if (isx) {
+          if (xfold) { ky = gi / xg; kx = 1; q = gi % xg; }
+          else { const int tp = gi / xg; q = gi % xg; ky = tp / 3; kx = tp % 3; }
+        } else {
+          const int gj = gi - ngx, tp = gj / hg; q = gj % hg; ky = tp / 3; kx = tp % 3;
+        }
+      };
+      if (ii < ntg) {
+        const int e = ii % E::EPL;
+        size_t r = ii / E::EPL;
+        const int lane = r % 64; r /= 64;
+        const int tl = r % 2;
+        const int s = (int)(r / 2);
+        const int gi = 4 * s + (lane >> 4), m = lane & 15;          // the lane's K group; output row m of column tile tl
+        const int gate = m % 4, ch = 2 * (m / 4) + tl;               // row = 4 c + gate, channel = 2 c + tile
+        float v = 0.f;
+        if (gi < ng && ch < Ch) {
+          int ky, kx, q; bool isx;
+          group(gi, ky, kx, q, isx);
+          const int c = q * E::EPL + e;                             // channel inside the pixel's (real) channels of that source
+          int ic = -1;
+          if (isx) {
+            if (xfold) { if (c < 3 * Cx) { kx = c / Cx; ic = c % Cx; } }
+            else if (c < Cx) ic = c;
+          } else if (c < Ch) {
+            ic = Cx + c;
+          }
+          if (ic >= 0) v = W[(((size_t)(gate * Ch + ch)) * Ctot + ic) * taps + ky * k + kx];
+        }
+        store_elem<DT>(Wt, ii, v);
+      } else {
+        // table[gi]: byte offset of the group inside its source's LDS halo image, relative to the lane's own pixel at tap (0, 0)
+        const int gi = (int)(ii - ntg);
+        int off = 0;
+        if (gi < ng) {
+          int ky, kx, q; bool isx;
+          group(gi, ky, kx, q, isx);
+          off = (ky * NINT_TINY_HW + kx) * (isx ? xg : hg) * 16 + q * 16;
+        }
+        ((int*)(Wt + (size_t)NINT_TINY_MAXSTEPS * 2 * 1024))[gi] = off;
+      }
+    } else if (i >= nf + nd + nb) {
       const size_t ii = i - nf - nd - nb;
       const int o = ii % 32, gate = o >> 3, ch = o & 7;
       int r = (int)(ii / 32);
@@ -443,7 +495,8 @@ extern "C" size_t nint_packed_weight_bytes(int Cx, int Ch, int k, int dtype, int
   // both images fit in (Cxp+Chp) x 4*Ch16 x taps elements (the folded forward image is smaller); tiny hidden widths keep the
   // stencil kernel's f32 weight rows behind them (csrc/stencil.hip)
   size_t n = (size_t)(Cxp + Chp) * 4 * Ch16 * k * k * es;
-  if (nint_stencil_shape(Cx, Ch, k, xfold)) n = nint_internal_stencil_offset(Cxp, Chp, Ch16, k, dtype) + (size_t)3 * nint_stencil_rows(Cx, Ch, xfold) * 128;
+  if (nint_stencil_shape(Cx, Ch, k, xfold))       // (+ the dense-K image of csrc/tiny_gemm.hip behind the stencil rows)
+    n = nint_internal_tiny_offset(Cx, Cxp, Ch, Chp, Ch16, k, xfold, dtype) + nint_tiny_bytes();
   return n;
 }
 
@@ -453,7 +506,8 @@ extern "C" int nint_pack_weights(const float* W, const float* bias, void* Wf, vo
   const int kc = nint_kc(dtype);
   if (kc < 0) return NINT_E_ARG;
   const int Cxp = nint_round_up(xfold ? k * Cx : Cx, kc), Chp = nint_round_up(Ch, kc), Ch16 = nint_round_up(Ch, 16);
-  const size_t n = 2 * (size_t)(Cxp + Chp) * 4 * Ch16 * k * k + 4 * Ch16 + 3 * 32 * (size_t)(nint_stencil_shape(Cx, Ch, k, xfold) ? nint_stencil_rows(Cx, Ch, xfold) : 0);
+  const size_t n = 2 * (size_t)(Cxp + Chp) * 4 * Ch16 * k * k + 4 * Ch16 + 3 * 32 * (size_t)(nint_stencil_shape(Cx, Ch, k, xfold) ? nint_stencil_rows(Cx, Ch, xfold) : 0)
+                   + (nint_tiny_shape(Cx, Ch, k, xfold, dtype) ? (size_t)NINT_TINY_MAXSTEPS * 2 * 64 * (dtype == NINT_BF16 ? 8 : 4) + 4 * NINT_TINY_MAXSTEPS : 0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == NINT_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<NINT_BF16>, grid1d(n), dim3(256), 0, st, W, bias, Wf, Wd, bias_p, Cx, Cxp, Ch, Ch16, Chp, k, xfold);
@@ -478,7 +532,8 @@ extern "C" int nint_pack_weights_layers(const float* const* W, const float* cons
       return NINT_E_ARG;
     t.e[l] = PackEntry{W[l], bias[l], (void*)ly.Wf, (void*)ly.Wd, (float*)ly.bias_p, ly.Cx, ly.Cxp, ly.Ch, ly.Ch16, ly.Chp, ly.k, ly.xfold};
     const size_t n = 2 * (size_t)(ly.Cxp + ly.Chp) * 4 * ly.Ch16 * ly.k * ly.k + 4 * ly.Ch16 +
-                     3 * 32 * (size_t)(nint_stencil_shape(ly.Cx, ly.Ch, ly.k, ly.xfold) ? nint_stencil_rows(ly.Cx, ly.Ch, ly.xfold) : 0);
+                     3 * 32 * (size_t)(nint_stencil_shape(ly.Cx, ly.Ch, ly.k, ly.xfold) ? nint_stencil_rows(ly.Cx, ly.Ch, ly.xfold) : 0) +
+                     (nint_tiny_shape(ly.Cx, ly.Ch, ly.k, ly.xfold, dtype) ? (size_t)NINT_TINY_MAXSTEPS * 2 * 64 * (dtype == NINT_BF16 ? 8 : 4) + 4 * NINT_TINY_MAXSTEPS : 0);
     if (n > nmax) nmax = n;
   }
   dim3 grid = grid1d(nmax);

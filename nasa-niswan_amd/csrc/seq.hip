@@ -173,8 +173,12 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
         lt[n][0] = l; lt[n][1] = t; ++n;
       }
       rc = n > 1 ? NINT_OK : NINT_E_SHAPE;
+      nint_layer ly8[NINT_MULTI_MAX];
       for (int q = 0; q < n && rc == NINT_OK; ++q) {
-        const CellFwdJob j = job(lt[q][0], lt[q][1]);
+        CellFwdJob j = job(lt[q][0], lt[q][1]);
+        if (s->wave == 4) {                    // (experiment: every problem of the merged grid on 8-row tiles -- the grid runs at two workgroups per CU anyway)
+          ly8[q] = *j.ly; ly8[q].tile_rows = 8; j.ly = &ly8[q];
+        }
         rc = nint_internal_cell_fwd_plan(&j, g, s->dtype, B, &plans[q]);
       }
       if (rc == NINT_OK) rc = nint_internal_conv_multi(plans, n, s->dtype, stream);

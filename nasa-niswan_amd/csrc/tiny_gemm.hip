@@ -37,7 +37,14 @@ struct TinyArgs {
   int H, W, P, Hh, Wh, tiles_x, tiles_y;
 };
 
-constexpr int TG_ROWS = 8, TG_COLS = 32, TG_HW = TG_COLS + 2, TG_HH = TG_ROWS + 2, TG_MAXSTEPS = 12;
+constexpr int TG_ROWS = 8, TG_COLS = 32, TG_HW = NINT_TINY_HW, TG_HH = TG_ROWS + 2, TG_MAXSTEPS = NINT_TINY_MAXSTEPS;
+static_assert(TG_HW == TG_COLS + 2, "the packer's group table uses this halo width");
+
+// two adjacent channels (even index) in one store: 8 bytes f32 / 4 bytes bf16
+template <int DT> __device__ __forceinline__ void store_pair(void* p, size_t i, float v0, float v1) {
+  if constexpr (DT == NINT_BF16) *(uint32_t*)((uint16_t*)p + i) = pack_bf16x2(v0, v1);
+  else *(float2*)((float*)p + i) = make_float2(v0, v1);
+}
 
 template <int DT>
 __global__ __launch_bounds__(256) void tiny_lstm_kernel(TinyArgs a) {
@@ -140,8 +147,8 @@ __global__ __launch_bounds__(256) void tiny_lstm_kernel(TinyArgs a) {
     const size_t pix = ((size_t)img * a.H + y) * a.W + x;
     float cp0 = 0.f, cp1 = 0.f;
     if (a.c_prev && ch0 < Ch) {
-      const float* cpp = a.c_prev + pix * a.Chp + ch0;
-      cp0 = cpp[0]; cp1 = cpp[1];                              // (channel ch0 + 1 may be padding: the slab holds a zero there)
+      const float2 cpp = *(const float2*)(a.c_prev + pix * a.Chp + ch0);   // (channel ch0 + 1 may be padding: the slab holds a zero there)
+      cp0 = cpp.x; cp1 = cpp.y;
     }
     float gi[2], gf[2], gg[2], go[2], cn[2], hn[2];
 #pragma unroll
@@ -154,25 +161,21 @@ __global__ __launch_bounds__(256) void tiny_lstm_kernel(TinyArgs a) {
       hn[t2] = go[t2] * tanhf_(cn[t2]);                        // model.py:229
     }
     if (ch0 < Ch) {                                            // (a half-empty pair: its padding channel is an exact zero)
-      float* co = a.c_out + pix * a.Chp + ch0;
-      co[0] = cn[0]; co[1] = cn[1];
+      *(float2*)(a.c_out + pix * a.Chp + ch0) = make_float2(cn[0], cn[1]);
       char* ho = a.h_out + ((((size_t)img * a.Hh) + (y + a.P)) * a.Wh + (x + a.P)) * a.Chp * E::ES;
-      store_elem<DT>(ho, ch0, hn[0]); store_elem<DT>(ho, ch0 + 1, hn[1]);
+      store_pair<DT>(ho, ch0, hn[0], hn[1]);
     }
     if (a.gates_out) {
       char* gs = a.gates_out + pix * 4 * a.Ch16 * E::ES;       // column (cblock 0 * 4 + gate) * 16 + ch
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        store_elem<DT>(gs, 0 + ch0 + t2, gi[t2]);
-        store_elem<DT>(gs, 16 + ch0 + t2, gf[t2]);
-        store_elem<DT>(gs, 32 + ch0 + t2, gg[t2]);
-        store_elem<DT>(gs, 48 + ch0 + t2, go[t2]);
-        // columns 8 .. 15 of every gate block: the values of a channel with zero weights (the stash is not pre-initialised)
-        store_elem<DT>(gs, 0 + 8 + ch0 + t2, 0.5f);
-        store_elem<DT>(gs, 16 + 8 + ch0 + t2, 0.5f);
-        store_elem<DT>(gs, 32 + 8 + ch0 + t2, 0.f);
-        store_elem<DT>(gs, 48 + 8 + ch0 + t2, 0.5f);
-      }
+      store_pair<DT>(gs, 0 + ch0, gi[0], gi[1]);
+      store_pair<DT>(gs, 16 + ch0, gf[0], gf[1]);
+      store_pair<DT>(gs, 32 + ch0, gg[0], gg[1]);
+      store_pair<DT>(gs, 48 + ch0, go[0], go[1]);
+      // columns 8 .. 15 of every gate block: the values of a channel with zero weights (the stash is not pre-initialised)
+      store_pair<DT>(gs, 0 + 8 + ch0, 0.5f, 0.5f);
+      store_pair<DT>(gs, 16 + 8 + ch0, 0.5f, 0.5f);
+      store_pair<DT>(gs, 32 + 8 + ch0, 0.f, 0.f);
+      store_pair<DT>(gs, 48 + 8 + ch0, 0.5f, 0.5f);
     }
   }
 }
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void tiny_lstm_kernel(TinyArgs a) {
 int nint_internal_tiny_lstm(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* x_slab,
                             const void* h_prev, const float* c_prev, void* h_out, float* c_out, void* gates_out,
                             void* stream) {
-  if (!ly || !nint_stencil_shape(ly->Cx, ly->Ch, ly->k, ly->xfold) || g->P < 1) return NINT_E_SHAPE;
+  if (!ly || !nint_tiny_shape(ly->Cx, ly->Ch, ly->k, ly->xfold, dtype) || g->P < 1) return NINT_E_SHAPE;
   const int es = dtype == NINT_BF16 ? 2 : 4;
   TinyArgs a = {};
   a.xs = (const char*)x_slab; a.hs = (const char*)h_prev;
@@ -190,7 +193,6 @@ int nint_internal_tiny_lstm(const nint_layer* ly, const nint_geom* g, int dtype,
   a.xg = nint_tiny_xg(ly->Cx, ly->xfold, dtype); a.hg = nint_tiny_hg(ly->Ch, dtype);
   a.ngx = nint_tiny_ngx(ly->Cx, ly->xfold, dtype);
   a.ngroups = a.ngx + 9 * a.hg;
-  if ((a.ngroups + 3) / 4 > TG_MAXSTEPS) return NINT_E_SHAPE;
   const size_t off = nint_internal_tiny_offset(ly->Cx, ly->Cxp, ly->Ch, ly->Chp, ly->Ch16, ly->k, ly->xfold, dtype);
   a.Wt = (const char*)ly->Wf + off;
   a.table = (const int*)(a.Wt + (size_t)TG_MAXSTEPS * 2 * 1024);

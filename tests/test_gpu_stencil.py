@@ -1,8 +1,11 @@
-"""The vector-ALU stencil path of the gate step (csrc/stencil.hip) -- SURVEY.md section 7 step 4 / north_star: "MFMA used only
+"""The tiny-layer paths of the gate step: the dense-K MFMA kernel (csrc/tiny_gemm.hip, the library's choice) and the
+vector-ALU stencil kernel (csrc/stencil.hip) -- SURVEY.md section 7 step 4 / north_star: "MFMA used only
 ... when channel count makes it a real dense contraction", reference op model.py:207-231 with ConvLSTM(4, [8], [3], 1)
 (BASELINE configs[0]).  nint_cell_fwd takes it for nint_layer.tile_rows == 1 ("one pixel per lane") on layers with Ch <= 8,
-k = 3 and thin inputs -- so every shape here runs BOTH families: the stencil kernel (engine.FORCE_TILE_ROWS = 1) and the
-implicit-GEMM kernel (engine.FORCE_TILE_ROWS = 8), each against the CPU oracle (prediction, loss-weighted gradients of every parameter and of the
+k = 3 and thin inputs; left to itself (tile_rows == 0) the library runs such layers on the matrix pipe with a DENSE K (16-byte
+channel groups of the staged halo tile gathered by the four lane groups of one fragment read: 4 K-steps instead of 12 for
+configs[0]) -- so every shape here runs THREE families: the dense-K kernel (engine.FORCE_TILE_ROWS = 0), the stencil kernel
+(= 1) and the padded implicit-GEMM kernel (= 8), each against the CPU oracle (prediction, loss-weighted gradients of every parameter and of the
 input) and against each other.
 
 Tolerances: f32 outputs rtol 1e-4 / atol 1e-5 and gradients max-abs <= 1e-3 max|g| against the oracle, the two families within
@@ -75,8 +78,9 @@ def test_stencil_and_gemm_families_against_the_oracle_and_each_other(pkg, name, 
         ref["grad." + k] = leaf[k].grad
     st, held = _run(pkg, params, C_, hidden, X, wgt, dtype, 1)
     mm, _ = _run(pkg, params, C_, hidden, X, wgt, dtype, 8)
+    dk, _ = _run(pkg, params, C_, hidden, X, wgt, dtype, 0)
     assert all(held), (name, held)                               # every layer of these stacks is a stencil shape
-    for fam, res in (("stencil", st), ("gemm", mm)):
+    for fam, res in (("dense-K", dk), ("stencil", st), ("gemm", mm)):
         for k, a in res.items():
             a, b = a.double(), ref[k].double()
             assert torch.isfinite(a).all(), (fam, k)
@@ -89,8 +93,9 @@ def test_stencil_and_gemm_families_against_the_oracle_and_each_other(pkg, name, 
                 e = float((a - b).norm() / (b.norm() + 1e-30))
                 assert e <= 2e-2, (fam, k, e)
     d = float((st["pred"].double() - mm["pred"].double()).abs().max() / mm["pred"].double().abs().max())
-    print(f"  {name} {dtype}: stencil vs gemm prediction, max diff / max = {d:.2e}")
-    assert d <= (1e-5 if dtype == "f32" else 2e-2), (name, d)
+    d2 = float((dk["pred"].double() - mm["pred"].double()).abs().max() / mm["pred"].double().abs().max())
+    print(f"  {name} {dtype}: prediction, max diff / max: stencil vs gemm {d:.2e}, dense-K vs gemm {d2:.2e}")
+    assert d <= (1e-5 if dtype == "f32" else 2e-2) and d2 <= (1e-5 if dtype == "f32" else 2e-2), (name, d, d2)
 
 
 def test_stencil_choice_is_host_arithmetic(pkg):
