@@ -160,9 +160,9 @@ def parse_args(argv=None):
     ap.add_argument("--fuse-bwd", type=lambda v: int(v, 0), default=0,
                     help="nint_seq.fuse_bwd (BPTT schedule; 0 = the library's per-layer choice, 0x40000000|masks = explicit, see nint.h)")
     ap.add_argument("--wide", type=int, default=0, help="nint_layer.wide of every layer: weight-gradient kernel family (0 = the library's choice, 1 = 4-wave 64-column kernel, 2 = 8-wave 128-column kernel where instantiated)")
-    ap.add_argument("--wave", type=int, default=-1, choices=[-1, 0, 1, 2, 4],
+    ap.add_argument("--wave", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="merged grids (nint_seq.wave): -1 = the engine's rule by batch size, 0 = off, 1 = forward wavefront + backward pair, 2 = forward wavefront only")
-    ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 1, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape; 1 = the stencil gate kernel where it holds)")
+    ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 1, 2, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape; tiny layers: 1 = stencil gate kernel, 2 = dense-K MFMA gate kernel)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--phase-events", type=int, default=0, help="after the timed region, bracket the phases of this many more steps with HIP events (phase_ms in the line: pack+forward, head/loss, BPTT+weight gradients, all-reduce+Adam)")

@@ -59,8 +59,10 @@ typedef struct nint_layer {
   int32_t Cx, Cxp;        /* input channels / padded to KC */
   int32_t Ch, Ch16, Chp;  /* hidden channels / padded to 16 / padded to KC */
   int32_t k;              /* odd kernel size, padding k/2 (model.py:204) */
-  int32_t tile_rows;      /* rows of the gate / dgrad kernels' pixel tile: 0 = chosen per launch shape, or 4 / 8; 1 = one pixel per
-                           * LANE: the vector-ALU stencil gate kernel (csrc/stencil.hip) where nint_stencil_holds(), else as 0 */
+  int32_t tile_rows;      /* rows of the gate / dgrad kernels' pixel tile: 0 = chosen per launch shape, or 4 / 8.  Tiny layers
+                           * (nint_stencil_holds()) have two more gate kernels: 1 = one pixel per LANE, the vector-ALU stencil
+                           * kernel (csrc/stencil.hip); 2 = the matrix pipe with a dense K (csrc/tiny_gemm.hip; also the library's
+                           * choice for such layers in f32 storage).  On other layers 1 / 2 mean 0. */
   int32_t xfold;          /* 1: the x source is HORIZONTALLY FOLDED (thin inputs, first layer only): slab channel
                            * kx*Cx + c holds x[.., x + kx - k/2][c] (0 outside the image), Cxp = roundup(k*Cx, KC), and
                            * the x part of K is k vertical taps x k*Cx channels instead of k*k taps x Cx channels padded

@@ -29,8 +29,11 @@ enum { EPI_LSTM = 0, EPI_DGRAD = 1, EPI_DGRAD_PW = 2 };
 
 // The library's own choice between the stencil kernel and the padded MFMA tiles for layers both hold (tile_rows == 0).
 // Measured on the full 100 x 154 grid, B = 8, configs[0]'s layer (4 -> 8, 3x3): see DESIGN.md section 6.
+// ... and between the dense-K MFMA kernel (csrc/tiny_gemm.hip) and the padded tiles: measured on the same launch (configs[0]'s layer,
+// full grid, B = 8, profiles/r04_d_tiny_layer_families.txt): f32 34.0 against 45.7 us, bf16 23.9 against 22.0 us -- both bf16 forms
+// sit on the slab layout's channel padding (the epilogue's partial-line stores), not on their matrix work.
 #ifndef NINT_TINY_AUTO
-#define NINT_TINY_AUTO true
+#define NINT_TINY_AUTO(dtype) ((dtype) == NINT_F32)
 #endif
 #ifndef NINT_STENCIL_AUTO
 #define NINT_STENCIL_AUTO(dtype) false
@@ -752,6 +755,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_multi8_kernel(ConvMulti m) {
   NINT_MULTI_PROLOGUE
   switch (m.variant[i]) {
     NINT_MULTI_CASE8(EPI_DGRAD, 1, 4, 4)
+    NINT_MULTI_CASE8(EPI_DGRAD_PW, 1, 4, 3)
     NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 4)
     NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 2)
     NINT_MULTI_CASE(EPI_DGRAD_PW, 1, 4, 3)
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_multi8_kernel(ConvMulti m) {
 static bool multi_holds(int variant) {
   switch (variant) {
     case conv_variant(EPI_LSTM, 4, 1, 4, 8): case conv_variant(EPI_DGRAD, 1, 4, 4, 8):      // (the *_multi8 kernels)
-    case conv_variant(EPI_LSTM, 2, 2, 4, 8): case conv_variant(EPI_LSTM, 1, 4, 4, 8):
+    case conv_variant(EPI_LSTM, 2, 2, 4, 8): case conv_variant(EPI_LSTM, 1, 4, 4, 8): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 8):
     case conv_variant(EPI_LSTM, 4, 1, 4, 4): case conv_variant(EPI_LSTM, 2, 2, 4, 4): case conv_variant(EPI_LSTM, 1, 4, 4, 4):
     case conv_variant(EPI_DGRAD, 1, 4, 4, 4): case conv_variant(EPI_DGRAD, 1, 4, 2, 4): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 4):
       return true;
@@ -878,7 +882,7 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
   if (!ly || !g || !x_slab || !h_out || !c_out || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   if (!(ly->k & 1) || ly->k / 2 > g->P) return NINT_E_ARG;
-  if (ly->tile_rows != 0 && ly->tile_rows != 1 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
+  if (ly->tile_rows != 0 && ly->tile_rows != 1 && ly->tile_rows != 2 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
   if (!aligned16(x_slab) || !aligned16(h_prev) || !aligned16(ly->Wf) || !aligned16(h_out)) return NINT_E_ALIGN;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   if (ly->Cxp % kc || ly->Chp % kc || ly->Ch16 % 16 || ly->Chp < ly->Ch16) return NINT_E_ARG;
@@ -901,7 +905,7 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
   a.bias = ly->bias_p;
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = (char*)h_out; a.gates_out = (char*)gates_out;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
-  a.tile_rows = ly->tile_rows == 1 ? 0 : ly->tile_rows;
+  a.tile_rows = ly->tile_rows <= 2 ? 0 : ly->tile_rows;
   hipStream_t st = (hipStream_t)stream;
   if (ly->wide < 0 || ly->wide > 2) return NINT_E_ARG;   // (the weight-gradient family switch: nothing to do with this launch)
   // tiny hidden widths (4*Ch <= 32 gate columns: no dense contraction): the VALU stencil kernel (csrc/stencil.hip) -- on request
@@ -912,7 +916,7 @@ static int cell_fwd(const nint_layer* ly, const nint_geom* g, int dtype, int N,
     return nint_internal_stencil_lstm(ly, g, dtype, N, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
   }
   // ... and the library's own choice for such layers: the matrix pipe with a DENSE K (csrc/tiny_gemm.hip)
-  if (ly->tile_rows == 0 && NINT_TINY_AUTO && nint_tiny_shape(ly->Cx, ly->Ch, ly->k, ly->xfold, dtype)) {
+  if ((ly->tile_rows == 2 || (ly->tile_rows == 0 && NINT_TINY_AUTO(dtype))) && nint_tiny_shape(ly->Cx, ly->Ch, ly->k, ly->xfold, dtype)) {
     if (plan) return NINT_E_SHAPE;
     return nint_internal_tiny_lstm(ly, g, dtype, N, x_slab, h_prev, c_prev, h_out, c_out, gates_out, stream);
   }
@@ -982,7 +986,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   if (pw && !pw->gates && !pw->lo_gates) return NINT_E_ARG;
   if (!dx_accum && !dh_prev && !pw) return NINT_OK;
   if (!aligned16(dG) || !aligned16(ly->Wd)) return NINT_E_ALIGN;
-  if (ly->tile_rows != 0 && ly->tile_rows != 1 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
+  if (ly->tile_rows != 0 && ly->tile_rows != 1 && ly->tile_rows != 2 && ly->tile_rows != 4 && ly->tile_rows != 8) return NINT_E_ARG;
   const int es = dtype == NINT_BF16 ? 2 : 4, kc = dtype == NINT_BF16 ? 32 : 16;
   const int Gc = 4 * ly->Ch16;
   ConvArgs a = {};
@@ -1001,7 +1005,7 @@ int nint_internal_conv_dgrad(const nint_layer* ly, const nint_geom* g, int dtype
   a.out0_overwrite = overwrite_dx ? 1 : 0;
   a.C0p = ly->Cxp; a.C1p = ly->Chp;
   a.Chp = ly->Chp; a.Ch16 = ly->Ch16;
-  a.tile_rows = ly->tile_rows == 1 ? 0 : ly->tile_rows;    // (1 = the stencil GATE kernel: the backward launches take their own choice)
+  a.tile_rows = ly->tile_rows <= 2 ? 0 : ly->tile_rows;    // (1 / 2 = the stencil / dense-K GATE kernels: the backward launches take their own choice)
   // only the n-tiles whose destination exists are computed (fused: the Ch16 real hidden columns, not their padding)
   const int nt_x = ly->Cxp / 16, nt_h = (pw && pw->gates) ? ly->Ch16 / 16 : ly->Chp / 16;
   a.nt_begin = dx_accum ? 0 : nt_x;

@@ -176,7 +176,12 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
       nint_layer ly8[NINT_MULTI_MAX];
       for (int q = 0; q < n && rc == NINT_OK; ++q) {
         CellFwdJob j = job(lt[q][0], lt[q][1]);
-        if (s->wave == 4) {                    // (experiment: every problem of the merged grid on 8-row tiles -- the grid runs at two workgroups per CU anyway)
+        if ((s->wave == 2 || s->wave == 3) && j.ly->tile_rows == 0) {
+          // mid-size batches: the first layer's 8-row tiles make the merged grid a 256-register kernel at two workgroups per CU,
+          // where the narrow layers' 4-row tiles lose what they were chosen for (a third and fourth workgroup per CU): every
+          // problem of the grid takes 8-row tiles (half the weight bytes per MFMA).  Measured at B = 8, three fresh-process
+          // pairs: forward 2.84-2.86 -> 2.71-2.72 ms, step 1018-1024 -> 1037-1042 samples/s (profiles/r04_d_wave_rows8.txt).
+          // Same K-slice structure per pixel: bit-identical to the time-major order.
           ly8[q] = *j.ly; ly8[q].tile_rows = 8; j.ly = &ly8[q];
         }
         rc = nint_internal_cell_fwd_plan(&j, g, s->dtype, B, &plans[q]);
@@ -255,7 +260,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // ADJACENT launches that share no buffer when the stack has three or more layers (the top layer's step touches its own
   // state and layer L-2's; the bottom dgrad reads dG[0] and writes dh[0] / dx): they go out as ONE grid
   // (nint_internal_conv_multi).  The bottom dgrad is held back (`pend`) until the next launch is known.
-  const bool merge = s->wave == 1 && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];   // (wave == 2: the forward wavefront only)
+  const bool merge = (s->wave == 1 || s->wave == 3) && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];   // (wave == 2: the forward wavefront only)
   struct { bool on; ConvPlan plan; const void* dG; void* dx; void* dh_prev; bool ow; } pend = {};
   auto flush = [&]() {                           // the held-back dgrad as a launch of its own
     if (!pend.on) return (int)NINT_OK;
@@ -338,6 +343,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
         if (pend.on && l == L - 1) {             // the top layer's step right behind the held-back bottom dgrad: one grid
           ConvPlan pl[2];
           pl[0] = pend.plan;
+          if (s->wave == 3) pw.tile_rows = 8;    // (experiment: the fused step on 8-row tiles inside the two-workgroups-per-CU grid)
           rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream, &pl[1]);
           if (rc != NINT_OK) return rc;
           rc = pl[1].gx > 0 ? nint_internal_conv_multi(pl, 2, s->dtype, stream) : NINT_E_SHAPE;

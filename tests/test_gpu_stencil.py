@@ -4,7 +4,7 @@ vector-ALU stencil kernel (csrc/stencil.hip) -- SURVEY.md section 7 step 4 / nor
 (BASELINE configs[0]).  nint_cell_fwd takes it for nint_layer.tile_rows == 1 ("one pixel per lane") on layers with Ch <= 8,
 k = 3 and thin inputs; left to itself (tile_rows == 0) the library runs such layers on the matrix pipe with a DENSE K (16-byte
 channel groups of the staged halo tile gathered by the four lane groups of one fragment read: 4 K-steps instead of 12 for
-configs[0]) -- so every shape here runs THREE families: the dense-K kernel (engine.FORCE_TILE_ROWS = 0), the stencil kernel
+configs[0]; its choice in f32 storage) -- so every shape here runs THREE families: the dense-K kernel (engine.FORCE_TILE_ROWS = 2), the stencil kernel
 (= 1) and the padded implicit-GEMM kernel (= 8), each against the CPU oracle (prediction, loss-weighted gradients of every parameter and of the
 input) and against each other.
 
@@ -78,7 +78,7 @@ def test_stencil_and_gemm_families_against_the_oracle_and_each_other(pkg, name, 
         ref["grad." + k] = leaf[k].grad
     st, held = _run(pkg, params, C_, hidden, X, wgt, dtype, 1)
     mm, _ = _run(pkg, params, C_, hidden, X, wgt, dtype, 8)
-    dk, _ = _run(pkg, params, C_, hidden, X, wgt, dtype, 0)
+    dk, _ = _run(pkg, params, C_, hidden, X, wgt, dtype, 2)
     assert all(held), (name, held)                               # every layer of these stacks is a stencil shape
     for fam, res in (("dense-K", dk), ("stencil", st), ("gemm", mm)):
         for k, a in res.items():
