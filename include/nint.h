@@ -118,9 +118,11 @@ typedef struct nint_seq {
                                         * calibration stamps (kind 0).  tag = kind | layer << 8 | t << 16 | end << 31 */
   int32_t probe_slots;
   /* Independent launches as ONE grid, for the strong-scaling shapes (B <= ~5 per GPU at 100 x 154), where one layer's launch
-   * does not fill 256 CUs.  wave = 1: both of the following; wave = 2: the forward wavefront only (mid-size batches -- B = 8 at
-   * 100 x 154 -- where the forward merge measured -3.4 % on the forward pass in every fresh process and the backward pair
-   * neutral with an occasional slow process, profiles/r04_c_wave_repeats.txt); 0: neither.
+   * does not fill 256 CUs.  wave = 1: both of the following; wave = 2: the forward wavefront only, every layer of the merged grid on
+   * 8-row tiles (mid-size batches -- B = 8 at 100 x 154 -- where the forward merge measured -3.4 % on the forward pass in every
+   * fresh process, another -5 % with the narrow layers on 8-row tiles, and the backward pair neutral with an occasional slow
+   * process: profiles/r04_c_wave_repeats.txt, r04_d_wave_rows8.txt; results = the time-major order's with tile_rows pinned to 8
+   * bit for bit, the default time-major order's to f32 rounding); 0: neither.
    *   nint_seq_fwd runs the (t, layer) wavefront (model.py:265-271: gate(l, t) needs gate(l-1, t) and gate(l, t-1) only, so
    *     gate(0, t+1), gate(1, t), gate(2, t-1) are independent): each wavefront step is one grid holding the workgroups of
    *     all its gate launches (T + L - 1 launches instead of T * L);
