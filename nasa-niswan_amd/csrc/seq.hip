@@ -153,8 +153,13 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
     j.gates_out = s->gates[l] ? (char*)s->gates[l] + (size_t)t * B * comp_px * 4 * ly->Ch16 * es : nullptr;
     return j;
   };
+  // wave = 2 / 3: every gate launch of the pass on 8-row tiles (the merged grids AND the lone launches at the ends of the
+  // wavefront, so that the pass equals the time-major order with tile_rows pinned to 8 bit for bit)
+  const bool rows8 = (s->wave == 2 || s->wave == 3) && L > 1 && L <= NINT_MULTI_MAX && !probe.buf;
   auto launch = [&](int l, int t) {
-    const CellFwdJob j = job(l, t);
+    CellFwdJob j = job(l, t);
+    nint_layer l8;
+    if (rows8 && j.ly->tile_rows == 0) { l8 = *j.ly; l8.tile_rows = 8; j.ly = &l8; }
     probe.stamp(NINT_PROBE_GATE, l, t, 0);
     const int r = nint_cell_fwd(j.ly, g, s->dtype, B, j.x_slab, j.h_prev, j.c_prev, j.h_out, j.c_out, j.gates_out, stream);
     probe.stamp(NINT_PROBE_GATE, l, t, 1);
@@ -176,12 +181,13 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
       nint_layer ly8[NINT_MULTI_MAX];
       for (int q = 0; q < n && rc == NINT_OK; ++q) {
         CellFwdJob j = job(lt[q][0], lt[q][1]);
-        if ((s->wave == 2 || s->wave == 3) && j.ly->tile_rows == 0) {
+        if (rows8 && j.ly->tile_rows == 0) {
           // mid-size batches: the first layer's 8-row tiles make the merged grid a 256-register kernel at two workgroups per CU,
           // where the narrow layers' 4-row tiles lose what they were chosen for (a third and fourth workgroup per CU): every
           // problem of the grid takes 8-row tiles (half the weight bytes per MFMA).  Measured at B = 8, three fresh-process
           // pairs: forward 2.84-2.86 -> 2.71-2.72 ms, step 1018-1024 -> 1037-1042 samples/s (profiles/r04_d_wave_rows8.txt).
-          // Same K-slice structure per pixel: bit-identical to the time-major order.
+          // = the time-major order with tile_rows pinned to 8, bit for bit; against the default order (4-row narrow tiles) the
+          // four K-slice partials of a pixel are summed in another order: f32 rounding.
           ly8[q] = *j.ly; ly8[q].tile_rows = 8; j.ly = &ly8[q];
         }
         rc = nint_internal_cell_fwd_plan(&j, g, s->dtype, B, &plans[q]);
