@@ -42,6 +42,7 @@ def test_xfold_pack_and_its_adjoint(lib, dt, Cc, W):
     kc = lib.nint_kc(dt)
     Cp = (k * Cc + kc - 1) // kc * kc
     es = 2 if dt else 4
+    torch.manual_seed(17)                    # (unseeded until round 4: the adjoint check below tripped once on a cancelling sum)
     x = torch.randn(B, T, Cc, H, W, device="cuda")
     slab = torch.zeros(T * B * g.Hh * g.Wh * Cp * es, dtype=torch.uint8, device="cuda")
     assert lib.nint_pack_btchw_xfold(P(x), P(slab), B, T, Cc, k, Cp, C.byref(g), dt, None) == 0
@@ -66,7 +67,9 @@ def test_xfold_pack_and_its_adjoint(lib, dt, Cc, W):
     fold = torch.cat([padx[:, :, :, kx:kx + W] for kx in range(k)], dim=1).permute(0, 2, 3, 1)
     lhs = float((fold.double() * G[..., :k * Cc].double()).sum())
     rhs = float((xr.double() * dx.double()).sum())
-    assert abs(lhs - rhs) <= 1e-6 * (abs(lhs) + 1.0)
+    # (dx is an f32 sum of k terms per element: the two inner products agree to f32 rounding of the terms, i.e. relative to
+    # the operands' norms, not to the -- possibly cancelling -- inner product itself)
+    assert abs(lhs - rhs) <= 1e-6 * float(fold.double().norm() * G[..., :k * Cc].double().norm())
 
 
 @pytest.mark.parametrize("dt", [0, 1])
