@@ -163,6 +163,7 @@ def parse_args(argv=None):
     ap.add_argument("--wave", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="merged grids (nint_seq.wave): -1 = the engine's rule by batch size, 0 = off, 1 = forward wavefront + backward pair, 2 = forward wavefront only")
     ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 1, 2, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape; tiny layers: 1 = stencil gate kernel, 2 = dense-K MFMA gate kernel)")
+    ap.add_argument("--overlap-allreduce", action="store_true", help="reduce the gradient bucket in two pieces, all but layer 0's slice under layer 0's weight gradient (FusedTrainer(overlap_allreduce=True))")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--phase-events", type=int, default=0, help="after the timed region, bracket the phases of this many more steps with HIP events (phase_ms in the line: pack+forward, head/loss, BPTT+weight gradients, all-reduce+Adam)")
@@ -287,7 +288,7 @@ def main():
         B = args.batch
     torch.manual_seed(0)                                    # identical init on every rank (utils.py:77-88)
     model = pkg.ConvLSTM(C, list(hidden), list(ks), len(hidden), out_channels=out, compute_dtype=args.dtype).to(dev)
-    trainer = FusedTrainer(model, lr=1e-3, betas=(0.5, 0.999), halo=halo, distributed=use_dist)
+    trainer = FusedTrainer(model, lr=1e-3, betas=(0.5, 0.999), halo=halo, distributed=use_dist, overlap_allreduce=args.overlap_allreduce)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)   # each rank its own shard of synthetic data
     X = torch.randn(B, T, C, Hp, Wp, device=dev, generator=gen)
     y = torch.randn(B, out, grid[0], grid[1], device=dev, generator=gen)
@@ -515,7 +516,7 @@ def main():
             "config": {"workload": args.workload, "in_channels": C, "hidden": list(hidden), "kernels": list(ks),
                        "out_channels": out, "seq_len": T, "padded_grid": [Hp, Wp], "grid": list(grid),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "wave": wave_on},
+                       "wave": wave_on, "overlap_allreduce": bool(args.overlap_allreduce)},
             # which build produced the line: the product library next to the package, or an A/B copy (--lib)
             "lib": os.path.realpath(args.lib) if args.lib else "product", "nint_version": int(pkg.load_library().nint_version()),
             # the same measurement over a window long enough that the timer does not matter (the headline window is 0.17 s)

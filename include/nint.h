@@ -131,6 +131,12 @@ typedef struct nint_seq {
    * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
    * not hold (the register-heavy fused shapes, more than 4 layers).  Ignored while probes are on. */
   int32_t wave;
+  /* nint_seq_bwd in two calls, for the data-parallel exchange: 0 = everything in one call; 1 = the BPTT chain and
+   * the weight / bias gradients of layers >= 1 (their fold included); 2 = the weight / bias gradient of layer 0 only (dG[0] of
+   * a preceding part-1 call on the same stream is its input).  Between the two the caller starts the all-reduce of everything
+   * but layer 0's slice of the gradient bucket, which then runs under layer 0's weight gradient -- the largest launches of the
+   * step -- instead of after them.  Same launches, same order inside each layer: bit-identical gradients. */
+  int32_t bwd_parts;
 } nint_seq;
 
 /* launch kinds for nint_seq.probe_mask / the probe tags */

@@ -39,7 +39,7 @@ class NintSeq(C.Structure):
                 ("dc", vp * NINT_MAX_LAYERS), ("dx", vp), ("dW", vp * NINT_MAX_LAYERS), ("db", vp * NINT_MAX_LAYERS),
                 ("wg_partial", vp), ("wg_partial_bytes", C.c_size_t), ("fuse_bwd", C.c_int32),
                 ("probe_mask", C.c_int32), ("probe", vp), ("probe_slots", C.c_int32),
-                ("wave", C.c_int32)]
+                ("wave", C.c_int32), ("bwd_parts", C.c_int32)]
 
 
 # every symbol include/nint.h declares: name -> (restype, argtypes)

@@ -231,6 +231,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   if (s->need_dx && !s->dx) return NINT_E_ARG;
   if (!s->wg_partial) return NINT_E_ARG;
   if (s->fuse_bwd < 0 || (s->fuse_bwd > 2 && !(s->fuse_bwd & 0x40000000))) return NINT_E_ARG;
+  if (s->bwd_parts < 0 || s->bwd_parts > 2) return NINT_E_ARG;
 
   // BPTT.  A layer runs either the CLASSIC step (pointwise backward of time u, then conv backward-data of time u) or the
   // FUSED step X[u] = conv backward-data of time u with the pointwise backward of time u-1 in its epilogue
@@ -273,7 +274,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     pend.on = false;
     return nint_internal_conv_dgrad(&s->layer[0], g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream);
   };
-  for (int so = T - 1; so >= -off[0]; --so) {
+  for (int so = T - 1; so >= -off[0] && s->bwd_parts != 2; --so) {      // (part 2: the chain ran in the part-1 call)
     for (int l = L - 1; l >= 0; --l) {
       const int u = so + off[l];
       if (u < 0 || u > (fused[l] ? T : T - 1)) continue;
@@ -383,8 +384,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     jobs[l] = WgJob{ly, s->T * B, s->dG[l], x_all, s->h[l] /* h_{t-1} = slab t */, s->dW[l], s->db[l],
                     s->has_init_state ? 0 : B};
   }
-  rc = nint_internal_conv_wgrad_multi(jobs, L, g, s->dtype, s->wg_partial, s->wg_partial_bytes, s->n_cu, stream,
-                                      probe.buf ? &probe : nullptr);
-  if (rc != NINT_OK) return rc;
+  // (bwd_parts: layers >= 1 in the first call, layer 0 in the second; each call folds what it reduced)
+  const int j0 = s->bwd_parts == 1 ? 1 : 0, j1 = s->bwd_parts == 2 ? 1 : L;
+  if (j1 > j0) {
+    rc = nint_internal_conv_wgrad_multi(jobs + j0, j1 - j0, g, s->dtype, s->wg_partial, s->wg_partial_bytes, s->n_cu, stream,
+                                        probe.buf ? &probe : nullptr);
+    if (rc != NINT_OK) return rc;
+  }
   return NINT_OK;
 }

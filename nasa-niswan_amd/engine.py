@@ -348,10 +348,13 @@ class SeqEngine:
         return dw.view(O, cfg.Ch, 1, 1), db
 
     def backward(self, ws: Workspace, need_dx: bool, zero_state_grads: Sequence[int] = (),
-                 dW_out: Optional[Sequence[torch.Tensor]] = None, db_out: Optional[Sequence[torch.Tensor]] = None):
+                 dW_out: Optional[Sequence[torch.Tensor]] = None, db_out: Optional[Sequence[torch.Tensor]] = None, parts: int = 0):
         """BPTT of model.py:253-271.  Precondition: ws.dh[l], ws.dc[l] hold dL/dh_{T-1}, dL/dc_{T-1}
         (layers listed in ``zero_state_grads`` start from zero state gradients instead).  Returns ([dW_l], [db_l], dx or None).
-        ``dW_out`` / ``db_out``: f32 contiguous destinations (e.g. views of a flat gradient bucket)."""
+        ``dW_out`` / ``db_out``: f32 contiguous destinations (e.g. views of a flat gradient bucket).
+        ``parts`` (nint_seq.bwd_parts): 0 = everything; 1 = the BPTT chain + the gradients of layers >= 1; 2 = layer 0's weight /
+        bias gradient only, after a parts = 1 call on the same workspace (the trainer starts the all-reduce of the rest of the
+        bucket in between)."""
         assert ws.train
         # layers in ``zero_state_grads`` start BPTT from zero dL/dh, dL/dc: flagged, not filled (the first BPTT step
         # then neither reads dc nor accumulates into dh).  The top layer's dh always holds the head's gradient.
@@ -379,7 +382,11 @@ class SeqEngine:
             dx = torch.empty(ws.T * ws.B * ws.H * ws.W * ws.Cxp0 * self.es, dtype=torch.uint8, device=self.device)   # ET compact
             s.dx = dx.data_ptr()
         s.need_dx = int(need_dx)
-        check(self.lib.nint_seq_bwd(C.byref(s), stream_ptr()), "nint_seq_bwd")
+        s.bwd_parts = int(parts)
+        try:
+            check(self.lib.nint_seq_bwd(C.byref(s), stream_ptr()), "nint_seq_bwd")
+        finally:
+            s.bwd_parts = 0
         s.dx = None
         dx_out = None
         if need_dx:

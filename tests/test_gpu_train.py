@@ -460,7 +460,7 @@ def test_thin_inputs_plain_layout_keeps_parity(pkg, dtype):
             engine.XFOLD = True
 
 
-def _ddp_rank(rank, world, port, out):
+def _ddp_rank(rank, world, port, out, overlap=False):
     """One rank of test_two_ranks_on_one_device_match_the_global_batch: gloo process group (it moves the device bucket through
     the host -- RCCL needs one device per rank), both ranks on cuda:0."""
     import torch.distributed as dist
@@ -471,7 +471,7 @@ def _ddp_rank(rank, world, port, out):
     from nasa_niswan_amd.utils import shard_indices
     torch.manual_seed(100 + rank)                     # deliberately different init per rank: the trainer broadcasts rank 0's
     net = p.ConvLSTM(6, [16, 8], [3, 3], 2, out_channels=2, compute_dtype="f32").cuda()
-    tr = FusedTrainer(net, lr=1e-2, halo=(2, 2))
+    tr = FusedTrainer(net, lr=1e-2, halo=(2, 2), overlap_allreduce=overlap)
     g = torch.Generator().manual_seed(7)
     X = torch.randn(4, 3, 6, 20, 28, generator=g)
     y = torch.randn(4, 2, 16, 24, generator=g)
@@ -512,3 +512,21 @@ def test_two_ranks_on_one_device_match_the_global_batch(pkg, tmp_path):
     assert err < 2e-5
     for a, b, c in zip(losses, r0["losses"], r1["losses"]):
         assert abs(a - (b + c) / 2) < 1e-5 * abs(a)
+
+
+def test_two_ranks_with_the_exchange_in_two_pieces_end_on_the_same_bits(pkg, tmp_path):
+    """FusedTrainer(overlap_allreduce=True): BPTT + the gradients of layers >= 1, then the all-reduce of everything but layer 0's
+    slice of the bucket STARTED (async), layer 0's weight gradient, the all-reduce of its slice (nint_seq.bwd_parts; SURVEY.md
+    8e).  Same launches per layer, two all-reduces of disjoint slices: after three steps the weights of both ranks equal the
+    one-all-reduce run's bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for overlap in (False, True):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        out = str(tmp_path / f"ddp{int(overlap)}")
+        mp.spawn(_ddp_rank, args=(2, port, out, overlap), nprocs=2, join=True)
+        res[overlap] = (torch.load(out + ".0"), torch.load(out + ".1"))
+    assert torch.equal(res[True][0]["w"], res[True][1]["w"])
+    assert torch.equal(res[True][0]["w"], res[False][0]["w"])
+    assert res[True][0]["losses"] == res[False][0]["losses"] and res[True][1]["losses"] == res[False][1]["losses"]
