@@ -265,7 +265,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
+    json_fd = None
     if use_dist:
+        # RCCL writes its version banner (five lines: "RCCL version : ...", "HIP version", ...) to STDOUT when the process group is
+        # created.  The contract is ONE JSON line there: file descriptor 1 goes to stderr for the rest of the run, and rank 0's
+        # line is written to a duplicate of the original stdout.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL on ROCm
@@ -548,7 +555,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.workload)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

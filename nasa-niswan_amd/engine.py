@@ -24,8 +24,8 @@ XFOLD = True
 # 64-column kernel, 2 = the 8-wave 128-column kernel wherever it is instantiated (tests run both against each other)
 FORCE_WIDE = 0
 FORCE_WAVE = None        # merged grids (nint_seq.wave): None = by batch size (SeqEngine._set_wave), 0 = never, 1 = forward wavefront + backward pair, 2 = forward wavefront only
-WAVE_TILES_PER_CU = 5     # ... both on while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs
-WAVE_FWD_TILES_PER_CU = 9 # ... the forward wavefront alone up to this (B = 8 at 100 x 154: 1000 tiles on 256 CUs)
+WAVE_TILES_PER_CU = 1.5   # ... both (4-row / per-shape tiles) while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs: B = 1 at 100 x 154
+WAVE_FWD_TILES_PER_CU = 9 # ... the forward wavefront alone, every layer on 8-row tiles, up to this (B = 2 ... 8 at 100 x 154: 250 ... 1000 tiles on 256 CUs)
 FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
 
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
@@ -257,7 +257,9 @@ class SeqEngine:
         if FORCE_WAVE is None:
             # round 4, six fresh processes per setting at B = 8 (profiles/r04_c_wave_repeats.txt): the forward wavefront as one
             # grid per step is 2.79-2.83 ms of forward against 2.87-2.94 in every process but one; the backward pair is neutral
-            # (4.82-4.93 against 4.84-4.92 ms) with one slow process in six (5.01): that pair was the "bimodal" of round 3
+            # (4.82-4.93 against 4.84-4.92 ms) with one slow process in six (5.01): that pair was the "bimodal" of round 3.
+            # Three fresh processes per mode and batch (profiles/r04_d_wave_small_batches.txt): B = 1: mode 1 647 samples/s
+            # against 586 (mode 2); B = 2: 833 against 841; B = 4: 957 against 966; B = 8: see above.
             mode = 1 if 2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu else (2 if 2 * tiles8 < WAVE_FWD_TILES_PER_CU * self.n_cu else 0)
         else:
             mode = int(FORCE_WAVE)

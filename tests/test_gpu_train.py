@@ -295,8 +295,10 @@ def test_bench_under_torchrun_with_rccl_group(pkg):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')][-1]
-    d = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    # ONE line on stdout: RCCL's version banner ("RCCL version : ...", five lines at process-group creation) goes to stderr
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[:1500]
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1" and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     # the collective by itself: timed on the step's stream around dist.all_reduce of the flat bucket
