@@ -45,7 +45,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
 XGMI_LINK_GBS = 153.0          # per-link, per direction (task statement: 7 links x ~153 GB/s per GPU)
-PROBE_GATE, PROBE_POINTWISE, PROBE_DGRAD, PROBE_FUSED, PROBE_WGRAD, PROBE_FOLD = 1, 2, 3, 4, 5, 6   # include/nint.h NINT_PROBE_*
+PROBE_GATE, PROBE_POINTWISE, PROBE_DGRAD, PROBE_FUSED, PROBE_WGRAD, PROBE_FOLD, PROBE_WAVE = 1, 2, 3, 4, 5, 6, 7   # include/nint.h NINT_PROBE_*
 
 
 def fwd_flops_per_sample(C, hidden, ks, out, T, Hp, Wp):
@@ -386,7 +386,7 @@ def main():
         # probe pass: PSTEPS more steps with stamps around the layer-0 gate / dgrad / pointwise launches, every layer's
         # weight-gradient block and the fold.  EVERY rank runs the steps (each ends in the all-reduce); rank 0 alone stamps.
         pbuf = torch.zeros(2 * SLOTS, dtype=torch.int64, device=dev) if rank == 0 else None
-        mask = (1 << PROBE_GATE) | (1 << PROBE_POINTWISE) | (1 << PROBE_DGRAD) | (1 << PROBE_FUSED) | (1 << PROBE_WGRAD) | (1 << PROBE_FOLD)
+        mask = (1 << PROBE_GATE) | (1 << PROBE_POINTWISE) | (1 << PROBE_DGRAD) | (1 << PROBE_FUSED) | (1 << PROBE_WGRAD) | (1 << PROBE_FOLD) | (1 << PROBE_WAVE)
         st_ = torch.cuda.current_stream()
 
         def ev_timer():
@@ -437,8 +437,7 @@ def main():
             tr = traffic.get(f"{args.workload}/{args.dtype}/B{B}/{key}", {}).get("bytes_per_launch")
             e = {"kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": pk, "unit": unit,
                  "frac": round(ach / pk, 4), "traffic": tr, "ms_per_launch": round(use, 4),
-                 "timing": ("in-step (nint_seq.probe stamps" + ("; time-major launches, the timed steps ran merged grids)" if wave_on else ")"))
-                           if ms is not None else "warm loop (HIP events)",
+                 "timing": "in-step (nint_seq.probe stamps)" if ms is not None else "warm loop (HIP events)",
                  "ms_per_launch_loop": round(ms_loop, 4), "frac_loop": round(ach / pk * use / ms_loop, 4),
                  ("flops_per_launch" if bound == "mfma" else "bytes_per_launch"): work}
             if note:
@@ -479,12 +478,37 @@ def main():
         us_wg, _ = mean_us(PROBE_WGRAD, 0)
         us_fold, _ = mean_us(PROBE_FOLD, 0)
         ms_ = lambda us: None if us is None else us * 1e-3
-        roof = entry("conv_igemm_fwd_layer0", "layer-0 gate kernel, LSTM epilogue (B images, one time step, full K)", "mfma",
-                     f_gate, ms_(us_gate), time_kernel(k_fwd, 50, st),
-                     note=None if us_gate0 is None else f"t = 0 launch (x half of K only): {us_gate0:.1f} us in the step")
+        gate_loop = time_kernel(k_fwd, 50, st)
+        roof_gate = entry("conv_igemm_fwd_layer0", "layer-0 gate kernel, LSTM epilogue (B images, one time step, full K)", "mfma",
+                          f_gate, ms_(us_gate), gate_loop,
+                          note=None if us_gate0 is None else f"t = 0 launch (x half of K only): {us_gate0:.1f} us in the step")
+        roof = roof_gate
+        # With the forward wavefront merged (nint_seq.wave), the step's dominant kernel is the merged grid: one wavefront step --
+        # gate(0, w), gate(1, w-1), gate(2, w-2), ... -- per launch.  Priced over ALL merged launches of a step (the two partial
+        # ones at the ends of the wavefront included), so that ms_per_launch is comparable with the kernel's average duration in
+        # a rocprofv3 --kernel-trace --stats of the same command.
+        wave_rows = [(n_, w_, us) for key_, v_ in dur.items() if key_ != "cal_us" and key_[0] == PROBE_WAVE
+                     for (w_, us) in v_ for n_ in [key_[1]]]
+        roof_wave = None
+        if wave_rows and wave_on:
+            def gate_flops(l, t):
+                cin = C if l == 0 else hidden[l - 1]
+                return 2.0 * B * Hp * Wp * ks[l] ** 2 * (cin + (hidden[l] if t > 0 else 0)) * 4 * hidden[l]
+            Lm = len(hidden)
+            fl = [sum(gate_flops(l, w_ - l) for l in range(Lm) if 0 <= w_ - l < T) for (n_, w_, us) in wave_rows]
+            full = [(f, us) for f, (n_, w_, us) in zip(fl, wave_rows) if n_ == Lm]
+            ms_wave = float(np.mean([us for _, _, us in wave_rows])) * 1e-3
+            roof_wave = entry("conv_lstm_multi8_fwd_wavefront",
+                              "conv_lstm_multi8_kernel: one forward wavefront step as ONE grid (gate(0, w), gate(1, w-1), gate(2, w-2): every layer on 8-row tiles)",
+                              "mfma", float(np.mean(fl)), ms_wave, ms_wave,
+                              note=(f"average over the {len(wave_rows) // PSTEPS} merged launches of a step; the {len(full) // PSTEPS} launches that hold all "
+                                    f"{Lm} layers: {np.mean([f for f, _ in full]) / 1e9:.1f} GFLOP in {np.mean([us for _, us in full]):.1f} us; no stand-alone "
+                                    "loop exists for a merged grid (ms_per_launch_loop repeats the in-step figure); the layer-0 gate kernel "
+                                    f"alone, one launch per time step: {gate_loop * 1e3:.1f} us in a warm loop") if full else None)
+            roof = roof_wave
         wg_loop = time_kernel(k_wgrad, 10, st)
         roof_all = [
-            dict(roof, launches_per_step=T - 1 if us_gate is not None else T),
+            dict(roof, launches_per_step=(len(wave_rows) // PSTEPS) if roof_wave is not None else (T - 1 if us_gate is not None else T)),
             dict(entry("wgrad_layer0", "layer-0 weight gradient (bf16: wgrad_wide_kernel<5, 2>, the 8-wave 128-column kernel; f32: wgrad_kernel): x part over T steps + h part over T-1 steps (in the step, without the fold launch)",
                        "mfma", f_wgrad, ms_(us_wg), wg_loop * f_wgrad / f_wgrad_loop,
                        note=f"loop figure = the stand-alone entry (all T steps of both sources + the fold, {wg_loop:.3f} ms) scaled by the executed / nominal FLOPs"),
@@ -497,13 +521,12 @@ def main():
         eng.release(ws)
         # per (kind, layer) in-step totals: what the step spends where (microseconds per step)
         names = {PROBE_GATE: "gate", PROBE_POINTWISE: "pointwise", PROBE_DGRAD: "dgrad", PROBE_FUSED: "fused_bptt_step",
-                 PROBE_WGRAD: "wgrad", PROBE_FOLD: "fold"}
+                 PROBE_WGRAD: "wgrad", PROBE_FOLD: "fold", PROBE_WAVE: "fwd_wavefront_grid_of_"}
         phases = {"step_ms_with_probes": round(float(np.median(step_ms)), 3),
                   "probe_pair_cost_us": round(float(np.mean(dur.get("cal_us", [0.0]))), 2),
-                  # the probes bracket single launches, so the library runs the time-major order while they are on; when the
-                  # timed steps ran merged grids (config.wave: small batches) the figures below price the launches of the
-                  # time-major schedule, not the merged ones
-                  "wave": False, "schedule_differs_from_timed_steps": bool(wave_on),
+                  # with probes on the forward wavefront keeps its merged grids (bracketed as such); only the backward pair of
+                  # nint_seq.wave = 1 (small batches) is enqueued as two launches while probes are on
+                  "wave": wave_on, "schedule_differs_from_timed_steps": wave_on == 1,
                   "per_step_us": {}}
         for key, v in sorted((k, v) for k, v in dur.items() if k != "cal_us"):
             phases["per_step_us"][f"{names[key[0]]}{key[1]}"] = {"launches": len(v) // PSTEPS,

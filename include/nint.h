@@ -129,7 +129,8 @@ typedef struct nint_seq {
    *   nint_seq_bwd enqueues the bottom layer's dgrad of one BPTT step together with the top layer's fused step of the next
    *     (adjacent launches that share no buffer in a stack of three or more layers).
    * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
-   * not hold (the register-heavy fused shapes, more than 4 layers).  Ignored while probes are on. */
+   * not hold (the register-heavy fused shapes, more than 4 layers).  With probes on the forward wavefront is kept (its merged
+   * grids are bracketed as NINT_PROBE_WAVE) and the backward pair is enqueued as two launches. */
   int32_t wave;
   /* nint_seq_bwd in two calls, for the data-parallel exchange: 0 = everything in one call; 1 = the BPTT chain and
    * the weight / bias gradients of layers >= 1 (their fold included); 2 = the weight / bias gradient of layer 0 only (dG[0] of
@@ -141,7 +142,8 @@ typedef struct nint_seq {
 
 /* launch kinds for nint_seq.probe_mask / the probe tags */
 enum { NINT_PROBE_CAL = 0, NINT_PROBE_GATE = 1, NINT_PROBE_POINTWISE = 2, NINT_PROBE_DGRAD = 3, NINT_PROBE_FUSED = 4,
-       NINT_PROBE_WGRAD = 5, NINT_PROBE_FOLD = 6 };
+       NINT_PROBE_WGRAD = 5, NINT_PROBE_FOLD = 6,
+       NINT_PROBE_WAVE = 7 /* a merged forward grid (nint_seq.wave): tag layer = number of gate launches in it, t = wavefront step */ };
 
 /* ---- library / device ---------------------------------------------------------------- */
 int nint_version(void);

@@ -155,7 +155,7 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   };
   // wave = 2 / 3: every gate launch of the pass on 8-row tiles (the merged grids AND the lone launches at the ends of the
   // wavefront, so that the pass equals the time-major order with tile_rows pinned to 8 bit for bit)
-  const bool rows8 = (s->wave == 2 || s->wave == 3) && L > 1 && L <= NINT_MULTI_MAX && !probe.buf;
+  const bool rows8 = (s->wave == 2 || s->wave == 3) && L > 1 && L <= NINT_MULTI_MAX;
   auto launch = [&](int l, int t) {
     CellFwdJob j = job(l, t);
     nint_layer l8;
@@ -165,7 +165,7 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
     probe.stamp(NINT_PROBE_GATE, l, t, 1);
     return r;
   };
-  if (s->wave && L > 1 && L <= NINT_MULTI_MAX && !probe.buf) {
+  if (s->wave && L > 1 && L <= NINT_MULTI_MAX) {
     // (t, layer) WAVEFRONT: step w runs gate(l, w - l) of every layer -- each needs gate(l-1, w-l) and gate(l, w-l-1), both
     // of step w-1 -- as ONE grid (conv_lstm_multi_kernel).  T + L - 1 launches instead of T * L; the same workgroups
     // on the same data, so the results are those of the time-major order bit for bit.
@@ -192,7 +192,11 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
         }
         rc = nint_internal_cell_fwd_plan(&j, g, s->dtype, B, &plans[q]);
       }
-      if (rc == NINT_OK) rc = nint_internal_conv_multi(plans, n, s->dtype, stream);
+      if (rc == NINT_OK) {
+        probe.stamp(NINT_PROBE_WAVE, n, w, 0);
+        rc = nint_internal_conv_multi(plans, n, s->dtype, stream);
+        probe.stamp(NINT_PROBE_WAVE, n, w, 1);         // (a shape the merged grid does not hold: an empty bracket, then the launches one by one)
+      }
       if (rc == NINT_E_SHAPE) {                // a shape the merged grid does not hold (or a single launch): one by one
         for (int q = 0; q < n; ++q) {
           rc = launch(lt[q][0], lt[q][1]);
