@@ -318,7 +318,9 @@ def test_bench_under_torchrun_with_rccl_group(pkg):
 def test_timing_probes_bracket_every_launch_and_change_nothing(pkg):
     """nint_seq.probe (how bench.py prices kernels inside the step): stamp launches around the selected launches of
     nint_seq_fwd / nint_seq_bwd.  They must not change a bit of the step's results, every (kind, layer, t) must appear as a
-    begin / end pair in launch order with non-decreasing timestamps, and a step without probes must leave the buffer alone."""
+    begin / end pair in launch order with non-decreasing timestamps, and a step without probes must leave the buffer alone.
+    The forward pass of this small batch is a wavefront of merged grids (nint_seq.wave = 1): those are bracketed as kind 7
+    (layer = gate launches in the grid, t = wavefront step), the lone launches at either end as gate launches."""
     import bench
     from nasa_niswan_amd.trainer import FusedTrainer
     from oracle import convlstm_oracle as O
@@ -332,7 +334,7 @@ def test_timing_probes_bracket_every_launch_and_change_nothing(pkg):
         tr = FusedTrainer(net, lr=1e-3, halo=(5, 5))
         buf = torch.zeros(2 * 1024, dtype=torch.int64, device="cuda")
         if probed:
-            tr.set_probe(buf, 0x7e)                  # every kind
+            tr.set_probe(buf, 0xfe)                  # every kind
         loss = float(tr.step(X.cuda(), y.cuda()))
         torch.cuda.synchronize()
         res[probed] = (loss, tr.flat.grad.clone(), tr.flat.data.clone(), buf.cpu().numpy())
@@ -341,15 +343,18 @@ def test_timing_probes_bracket_every_launch_and_change_nothing(pkg):
     w = res[True][3]
     fwd, bwd = bench.probe_table(w[:1024]), bench.probe_table(w[1024:])
     assert [r[:4] for r in fwd[:2]] == [(0, 0, 0, 0), (0, 0, 0, 1)] and [r[:4] for r in bwd[:2]] == [(0, 0, 0, 0), (0, 0, 0, 1)]
-    gates = [(r[1], r[2], r[3]) for r in fwd[2:]]
-    assert gates == [(l, t, e) for t in range(T) for l in range(3) for e in (0, 1)] and all(r[0] == 1 for r in fwd[2:])
+    exp = []
+    for w_ in range(T + 3 - 1):
+        ls = [l for l in range(3) if 0 <= w_ - l < T]
+        exp += [(7, len(ls), w_, e) for e in (0, 1)] if len(ls) > 1 else [(1, ls[0], w_ - ls[0], e) for e in (0, 1)]
+    assert [r[:4] for r in fwd[2:]] == exp
     for tab in (fwd, bwd):
         ticks = [r[4] for r in tab]
         assert all(b >= a for a, b in zip(ticks, ticks[1:])) and ticks[-1] > ticks[0]
     kinds = {r[0] for r in bwd[2:]}
     assert {2, 3, 5, 6} <= kinds                      # pointwise, dgrad, weight gradients, fold (the fused step: kind 4, per schedule)
     d = bench.probe_durations(w[:1024], w[1024:])
-    assert len(d[(1, 0)]) == T and all(us > 0 for _, us in d[(1, 0)]) and len(d[(5, 0)]) == 1
+    assert len(d[(1, 0)]) == 1 and len(d[(7, 3)]) == T - 2 and len(d[(7, 2)]) == 2 and all(us > 0 for _, us in d[(7, 3)]) and len(d[(5, 0)]) == 1
 
 
 def test_bench_starts_its_own_ranks(pkg):
