@@ -24,7 +24,7 @@ for path in sys.argv[2:]:
         name = blk.split("  grid=")[0]
         n = int(re.search(r"n=(\d+)", blk).group(1)) if re.search(r"n=(\d+)", blk) else 1
         for pre, (key, mult) in KEYS.items():
-            if name.startswith(pre) and key not in out:
+            if name.startswith(pre) and f"cfg1-20level/bf16/B8/{key}" not in out:
                 f = re.search(r"FETCH_SIZE\s+([\d.]+)", blk)
                 w = re.search(r"WRITE_SIZE\s+([\d.]+)", blk)
                 if f and w:
@@ -33,7 +33,7 @@ for path in sys.argv[2:]:
                     a = acc.setdefault((path, key), [0, 0.0, 0.0, mult])
                     a[0] += n; a[1] += n * float(f.group(1)); a[2] += n * float(w.group(1))
     for (pth, key), (n, fs, wsz, mult) in list(acc.items()):
-        if pth == path and key not in out and n:
+        if pth == path and f"cfg1-20level/bf16/B8/{key}" not in out and n:
             fk, wk = fs / n, wsz / n
             # (the stand-alone kbench passes list a layer-0 kernel first -- largest total -- and other layers' uses of the same
             # instantiation after it: only the merged grid is averaged over its grid sizes)
