@@ -130,7 +130,16 @@ typedef struct nint_seq {
    *     (adjacent launches that share no buffer in a stack of three or more layers).
    * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
    * not hold (the register-heavy fused shapes, more than 4 layers).  With probes on the forward wavefront is kept (its merged
-   * grids are bracketed as NINT_PROBE_WAVE) and the backward pair is enqueued as two launches. */
+   * grids are bracketed as NINT_PROBE_WAVE) and the backward pair is enqueued as two launches.
+   * wave = 4 (B = 2 ... 8 at 100 x 154): the forward pass of wave = 2, and in nint_seq_bwd the BOTTOM layer's dgrad of time u+1
+   *   waits for layer 1's dgrad of time u: one grid, the wide launch first, so that the narrow layer's workgroups fill its last
+   *   round (B = 2 / 4 / 8: +3.2 / +1.2 / +0.4 % on the step, fresh-process pairs, profiles/r04_f_wave4.txt).  Both launches
+   *   produce a piece of the bottom layer's d/dh of time u, so each stores its own (layer 1 into dh[0], the bottom layer into the
+   *   head of wg_partial, which is idle until the weight gradients) and the bottom layer's pointwise backward adds the two:
+   *   f32 = the time-major order bit for bit (the same f32 sum); bf16: each piece is rounded to bf16 before the f32 add instead
+   *   of the running sum after it (layer 0's gradients move by ~1e-3 relative).  Needs wg_partial_bytes >= B*H*W*Chp[0]*es,
+   *   classic (unfused) steps in layers 0 and 1, and no probes; otherwise the launches go out one by one.
+   *   (3: wave = 2 plus the backward pair of wave = 1 with the fused step on 8-row tiles: measured +0.2 ... +0.5 %, not used.) */
   int32_t wave;
   /* nint_seq_bwd in two calls, for the data-parallel exchange: 0 = everything in one call; 1 = the BPTT chain and
    * the weight / bias gradients of layers >= 1 (their fold included); 2 = the weight / bias gradient of layer 0 only (dG[0] of

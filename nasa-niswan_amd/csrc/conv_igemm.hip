@@ -746,6 +746,7 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_multi_kernel(ConvMulti m) {
   switch (m.variant[i]) {
     NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 4)
     NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 2)
+    NINT_MULTI_CASE(EPI_DGRAD, 2, 2, 3)
     NINT_MULTI_CASE(EPI_DGRAD_PW, 1, 4, 3)
     default: break;                            // (the register-heavy fused shapes -- 4 column tiles per wave -- would spill at 168 VGPRs)
   }
@@ -762,12 +763,25 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_multi8_kernel(ConvMulti m) {
     default: break;
   }
 }
+// the dgrad launches of two neighbouring layers (nint_seq.wave = 4: the bottom layer's of time u+1 with the next layer's of time
+// u), both on 8-row tiles.  A kernel of its own: as two more cases of the kernel above the register allocation of ALL its
+// bodies collapsed (1036 spilled registers).
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_multi8_kernel(ConvMulti m) {
+  NINT_MULTI_PROLOGUE
+  switch (m.variant[i]) {
+    NINT_MULTI_CASE8(EPI_DGRAD, 1, 4, 4)
+    NINT_MULTI_CASE8(EPI_DGRAD, 2, 2, 3)
+    default: break;
+  }
+}
 static bool multi_holds(int variant) {
   switch (variant) {
     case conv_variant(EPI_LSTM, 4, 1, 4, 8): case conv_variant(EPI_DGRAD, 1, 4, 4, 8):      // (the *_multi8 kernels)
     case conv_variant(EPI_LSTM, 2, 2, 4, 8): case conv_variant(EPI_LSTM, 1, 4, 4, 8): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 8):
     case conv_variant(EPI_LSTM, 4, 1, 4, 4): case conv_variant(EPI_LSTM, 2, 2, 4, 4): case conv_variant(EPI_LSTM, 1, 4, 4, 4):
     case conv_variant(EPI_DGRAD, 1, 4, 4, 4): case conv_variant(EPI_DGRAD, 1, 4, 2, 4): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 4):
+    case conv_variant(EPI_DGRAD, 2, 2, 3, 8): case conv_variant(EPI_DGRAD, 2, 2, 3, 4):      // (8-row: conv_dgrad_multi8_kernel)
       return true;
     default: return false;
   }
@@ -958,9 +972,16 @@ int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stre
   { auto kern = KERN_;                                                                                                                \
     if (lds > 64 * 1024) NINT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(kern, dim3(b), dim3(256), lds, st, m); }
-  bool rows8 = false;
+  bool rows8 = false, dpair = false;
   for (int i = 0; i < n; ++i) rows8 = rows8 || plans[i].variant % 10 == 2;
-  if (nfwd && rows8) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_F32>) }
+  for (int i = 0; i < n; ++i) dpair = dpair || plans[i].variant == conv_variant(EPI_DGRAD, 2, 2, 3, 8);
+  for (int i = 0; i < n; ++i)     // (the 4-row form of that shape is a case of conv_bwd_multi_kernel only, not of the 8-row kernel)
+    if (rows8 && plans[i].variant == conv_variant(EPI_DGRAD, 2, 2, 3, 4)) return NINT_E_SHAPE;
+  if (dpair)        // (conv_dgrad_multi8_kernel holds these two shapes only)
+    for (int i = 0; i < n; ++i)
+      if (plans[i].variant != conv_variant(EPI_DGRAD, 2, 2, 3, 8) && plans[i].variant != conv_variant(EPI_DGRAD, 1, 4, 4, 8)) return NINT_E_SHAPE;
+  if (dpair) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_dgrad_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_dgrad_multi8_kernel<NINT_F32>) }
+  else if (nfwd && rows8) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_F32>) }
   else if (nfwd) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_F32>) }
   else if (rows8) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_bwd_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_bwd_multi8_kernel<NINT_F32>) }
   else { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_bwd_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_bwd_multi_kernel<NINT_F32>) }

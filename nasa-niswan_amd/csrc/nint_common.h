@@ -166,7 +166,7 @@ struct Probe {
 // internal entry points shared between translation units (not part of the C ABI)
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
-                                     bool dc_zero, void* stream);
+                                     bool dc_zero, void* stream, const void* dh2 = nullptr);   // dh2: a second piece of d/dh, added
 struct WgJob {           // one layer's weight / bias gradient
   const nint_layer* ly; int N;
   const void* dG; const void* x_slab; const void* h_slab;

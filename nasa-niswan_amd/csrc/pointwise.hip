@@ -557,7 +557,7 @@ extern "C" int nint_pack_weights_layers(const float* const* W, const float* cons
 template <int DT>
 __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
                                           const float* __restrict__ c_new, const void* __restrict__ dh,
-                                          float* __restrict__ dc, void* __restrict__ dG,
+                                          const void* __restrict__ dh2, float* __restrict__ dc, void* __restrict__ dG,
                                           int N, int H, int W, int P, int Hh, int Wh, int Ch16, int Chp, int dc_zero) {
   const int nq = Ch16 >> 2;
   const size_t total = (size_t)N * H * W * nq;
@@ -580,7 +580,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __r
     f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
     if (c_prev) cp = *(const f32x4_t*)(c_prev + ci);
     const f32x4_t cn = *(const f32x4_t*)(c_new + ci);
-    const f32x4_t dhv = load_vec4<DT>(dh, ci);
+    f32x4_t dhv = load_vec4<DT>(dh, ci);
+    if (dh2) dhv += load_vec4<DT>(dh2, ci);      // d/dh in two pieces (nint_seq.wave = 4: the x columns of the layer above + the layer's own h columns)
     f32x4_t dcv = {0.f, 0.f, 0.f, 0.f};
     if (!dc_zero) dcv = *(const f32x4_t*)(dc + ci);
     f32x4_t o_i, o_f, o_g, o_o, dcp;
@@ -606,13 +607,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __r
 
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
-                                     bool dc_zero, void* stream) {
+                                     bool dc_zero, void* stream, const void* dh2) {
   if (!ly || !g || !gates || !c_new || !dh || !dc || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
   const size_t total = (size_t)N * g->H * g->W * (ly->Ch16 / 4);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid1d(total);
-#define NINT_PW(DT_) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<DT_>), grid, dim3(256), 0, st, gates, c_prev, c_new, dh, dc, dG, \
+#define NINT_PW(DT_) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<DT_>), grid, dim3(256), 0, st, gates, c_prev, c_new, dh, dh2, dc, dG, \
                                         N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp, dc_zero ? 1 : 0)
   if (dtype == NINT_BF16) NINT_PW(NINT_BF16); else NINT_PW(NINT_F32);
 #undef NINT_PW
@@ -623,7 +624,7 @@ int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, i
 extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                        const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                        void* stream) {
-  return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, false, stream);
+  return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, false, stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------ 1x1 head

@@ -155,7 +155,7 @@ extern "C" int nint_seq_fwd(const nint_seq* s, void* stream) {
   };
   // wave = 2 / 3: every gate launch of the pass on 8-row tiles (the merged grids AND the lone launches at the ends of the
   // wavefront, so that the pass equals the time-major order with tile_rows pinned to 8 bit for bit)
-  const bool rows8 = (s->wave == 2 || s->wave == 3) && L > 1 && L <= NINT_MULTI_MAX;
+  const bool rows8 = (s->wave == 2 || s->wave == 3 || s->wave == 4) && L > 1 && L <= NINT_MULTI_MAX;
   auto launch = [&](int l, int t) {
     CellFwdJob j = job(l, t);
     nint_layer l8;
@@ -271,7 +271,17 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // ADJACENT launches that share no buffer when the stack has three or more layers (the top layer's step touches its own
   // state and layer L-2's; the bottom dgrad reads dG[0] and writes dh[0] / dx): they go out as ONE grid
   // (nint_internal_conv_multi).  The bottom dgrad is held back (`pend`) until the next launch is known.
-  const bool merge = (s->wave == 1 || s->wave == 3) && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];   // (wave == 2: the forward wavefront only)
+  const int wv = s->wave;
+  const bool merge = (wv == 1 || wv == 3) && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];   // (wave == 2: the forward wavefront only)
+  // Mid-size batches (wave = 4): the bottom layer's dgrad of time u+1 waits for the dgrad of the layer above of time u instead and
+  // the two go out as one grid, the wide one first (the narrow layer's workgroups fill its last round: the forward wavefront's
+  // effect).  Both produce a piece of the bottom layer's d/dh of time u, so each stores its own -- the layer above into dh[0],
+  // the bottom layer into the head of the split-K scratch, which is idle until the weight gradients -- and the bottom layer's
+  // pointwise backward adds the two (f32: the same sum as the read-modify-write of the time-major order, bit for bit; bf16: each
+  // piece is rounded to bf16 before the f32 add instead of the running sum after it).
+  const size_t dh0_bytes = (size_t)B * comp_px * s->layer[0].Chp * es;
+  const bool merge_d = wv == 4 && L >= 2 && !probe.buf && !fused[0] && !fused[1] && !loc[0] && !loc[1] && s->wg_partial_bytes >= dh0_bytes;
+  void* const dh0_own = merge_d ? s->wg_partial : s->dh[0];
   struct { bool on; ConvPlan plan; const void* dG; void* dx; void* dh_prev; bool ow; } pend = {};
   auto flush = [&]() {                           // the held-back dgrad as a launch of its own
     if (!pend.on) return (int)NINT_OK;
@@ -289,11 +299,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       // c[l][0] is the (zero or given) initial state, so c_prev is always a valid pointer
       auto pointwise = [&](int t) {      // consumes dh[l] / dc[l] of time t, writes dG of time t
         // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
-        { const int rf = flush(); if (rf != NINT_OK) return rf; }
+        if (!merge_d || l == 0) { const int rf = flush(); if (rf != NINT_OK) return rf; }    // (wave = 4: the held-back launch touches layer 0 only)
         probe.stamp(NINT_PROBE_POINTWISE, l, t, 0);
         const int r = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, (const char*)s->gates[l] + (size_t)t * gs, s->c[l] + (size_t)t * cs,
                                                        s->c[l] + (size_t)(t + 1) * cs, s->dh[l], s->dc[l], (char*)s->dG[l] + (size_t)t * dgs,
-                                                       t == T - 1 && ((s->zero_dstate >> (2 * l)) & 1), stream);
+                                                       t == T - 1 && ((s->zero_dstate >> (2 * l)) & 1), stream,
+                                                       merge_d && l == 0 && t < T - 1 ? dh0_own : nullptr);
         probe.stamp(NINT_PROBE_POINTWISE, l, t, 1);
         return r;
       };
@@ -302,9 +313,9 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
                              : (s->need_dx ? (void*)((char*)s->dx + (size_t)u * B * comp_px * ly->Cxp * es) : nullptr);
       // ... stored where nothing else is there: dx; a dh flagged zero at the first step; a FUSED layer below (its dh
       // buffer only ever carries these columns).  Accumulated onto the h columns a classic layer below stored.
-      const bool ow = l == 0 ? true : (u == T - 1 ? (((s->zero_dstate >> (2 * (l - 1) + 1)) & 1) != 0) : fused[l - 1]);
+      const bool ow = l == 0 ? true : (u == T - 1 ? (((s->zero_dstate >> (2 * (l - 1) + 1)) & 1) != 0) : (fused[l - 1] || (merge_d && l == 1)));
       // at time 0 with a zero initial state nobody consumes d/dh_{-1}
-      void* dh_prev = (u == 0 && !s->has_init_state) ? nullptr : s->dh[l];
+      void* dh_prev = (u == 0 && !s->has_init_state) ? nullptr : (l == 0 && u > 0 ? dh0_own : s->dh[l]);   // (time 0: the caller reads d/dh_{-1} from dh[0])
       if (!fused[l]) {
         if (pw_done[l] != u) {                 // (else: the fused layer above already ran this pointwise backward)
           rc = pointwise(u);
@@ -322,9 +333,20 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           pw.tile_rows = 4;
           pw_done[l - 1] = u;
         }
-        rc = flush();
-        if (rc != NINT_OK) return rc;
-        if (merge && l == 0 && so > -off[0]) {  // (not the very last launch: there is a top-layer step to pair it with)
+        if (merge_d && l == 1 && pend.on) {       // the bottom layer's dgrad of the step before + this one: one grid
+          ConvPlan pl[2];
+          pl[0] = pend.plan;
+          rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, nullptr, stream, &pl[1]);
+          if (rc != NINT_OK) return rc;
+          rc = pl[1].gx > 0 ? nint_internal_conv_multi(pl, 2, s->dtype, stream) : NINT_E_SHAPE;
+          if (rc == NINT_OK) { pend.on = false; continue; }
+          if (rc != NINT_E_SHAPE) return rc;
+        }
+        if (!merge_d || l <= 1) {
+          rc = flush();
+          if (rc != NINT_OK) return rc;
+        }
+        if ((merge || merge_d) && l == 0 && so > -off[0]) {  // (not the very last launch: there is a top-layer step to pair it with)
           pend.dG = (const char*)s->dG[l] + (size_t)u * dgs; pend.dx = dx_dst; pend.dh_prev = dh_prev; pend.ow = ow;
           rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream, &pend.plan);
           if (rc != NINT_OK) return rc;
@@ -351,7 +373,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           pw.lo_dc_zero = u == T - 1 && ((s->zero_dstate >> (2 * (l - 1))) & 1);
           pw_done[l - 1] = u;
         }
-        if (pend.on && l == L - 1) {             // the top layer's step right behind the held-back bottom dgrad: one grid
+        if (merge && pend.on && l == L - 1) {    // the top layer's step right behind the held-back bottom dgrad: one grid
           ConvPlan pl[2];
           pl[0] = pend.plan;
           if (s->wave == 3) pw.tile_rows = 8;    // (experiment: the fused step on 8-row tiles inside the two-workgroups-per-CU grid)
@@ -361,14 +383,18 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           if (rc == NINT_OK) { pend.on = false; continue; }
           if (rc != NINT_E_SHAPE) return rc;
         }
-        rc = flush();
-        if (rc != NINT_OK) return rc;
+        if (!merge_d) {
+          rc = flush();
+          if (rc != NINT_OK) return rc;
+        }
         probe.stamp(NINT_PROBE_FUSED, l, u, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream);
         probe.stamp(NINT_PROBE_FUSED, l, u, 1);
       } else {
-        rc = flush();
-        if (rc != NINT_OK) return rc;
+        if (!merge_d) {
+          rc = flush();
+          if (rc != NINT_OK) return rc;
+        }
         probe.stamp(NINT_PROBE_DGRAD, l, 0, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l], dx_dst, dh_prev, ow, nullptr, stream);
         probe.stamp(NINT_PROBE_DGRAD, l, 0, 1);

@@ -1,0 +1,9 @@
+#!/bin/bash
+# lease R: wave = 4 against wave = 2, more fresh-process pairs at B = 8 and the smaller batches
+TAG=${1:-r4r}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+for b in 8 8 4 2; do for rep in 1 2 3; do for w in 2 4; do
+  timeout -k 10 300 python bench.py --batch $b --steps 60 --warmup 5 --no-cpu-baseline --no-kernel-rooflines --long-steps 0 --phase-events 30 --wave $w 2>> "$OUT/bench.err" | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); p=d['phase_ms']; print('B=$b wave=$w', d['value'], d['ms_per_step'], 'fwd', p['pack_forward'], 'bwd', p['bptt_wgrad_fold'])" || exit 1
+done; done; done | tee "$OUT/wave4_ab.txt"
