@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 109
+#define NINT_VERSION 110
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
 

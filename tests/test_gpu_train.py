@@ -308,9 +308,9 @@ def test_bench_under_torchrun_with_rccl_group(pkg):
     r = d["roofline"]
     assert r["timing"].startswith("in-step") and r["ms_per_launch"] > 0 and r["ms_per_launch_loop"] > 0
     ph = d["phases"]["per_step_us"]
-    # B = 2 runs the forward wavefront as merged grids (nint_seq.wave = 2): 10 grids of all three layers, one of two at either
+    # B = 2 runs the forward wavefront as merged grids (nint_seq.wave = 4): 10 grids of all three layers, one of two at either
     # end, the lone gate launches of the first / last wavefront step -- and the headline roofline is the merged grid's
-    assert d["config"]["wave"] == 2 and ph["fwd_wavefront_grid_of_3"]["launches"] == 10 and ph["fwd_wavefront_grid_of_2"]["launches"] == 2
+    assert d["config"]["wave"] == 4 and ph["fwd_wavefront_grid_of_3"]["launches"] == 10 and ph["fwd_wavefront_grid_of_2"]["launches"] == 2
     assert ph["gate0"]["launches"] == 1 and ph["gate2"]["launches"] == 1 and r["kernel"].startswith("conv_lstm_multi8_kernel")
     assert ph["wgrad0"]["launches"] == 1 and 0 < d["phases"]["probe_pair_cost_us"] < 50
 
