@@ -138,7 +138,10 @@ typedef struct nint_seq {
    *   head of wg_partial, which is idle until the weight gradients) and the bottom layer's pointwise backward adds the two:
    *   f32 = the time-major order bit for bit (the same f32 sum); bf16: each piece is rounded to bf16 before the f32 add instead
    *   of the running sum after it (layer 0's gradients move by ~1e-3 relative).  Needs wg_partial_bytes >= B*H*W*Chp[0]*es,
-   *   classic (unfused) steps in layers 0 and 1, and no probes; otherwise the launches go out one by one.
+   *   classic (unfused) steps in layers 0 and 1, and no probes; otherwise the launches go out one by one.  With a fused top
+   *   layer in a stack of three or more, the bottom layer's pointwise backward of time u ALSO waits -- for the top layer's fused
+   *   step of time u-1 (the next launch, and independent of it): one grid, the pointwise pass as a problem of the conv kernel
+   *   (bit-identical; B = 2 / 4 / 8: another +1.3 / +0.6 / +0.25 %).
    *   (3: wave = 2 plus the backward pair of wave = 1 with the fused step on 8-row tiles: measured +0.2 ... +0.5 %, not used.) */
   int32_t wave;
   /* nint_seq_bwd in two calls, for the data-parallel exchange: 0 = everything in one call; 1 = the BPTT chain and

@@ -700,6 +700,8 @@ struct ConvMulti {
   int nbx[NINT_MULTI_MAX];           // pixel-tile workgroups of each problem (its launch's gridDim.x); column group = (b - begin) / nbx
   int nwg[NINT_MULTI_MAX];           // nbx * column groups: workgroups past it are padding
   int variant[NINT_MULTI_MAX];
+  PwArgs pw;                         // conv_bwd_multi_kernel only: workgroups [begin[n], begin[n] + pw_blocks) run a pointwise LSTM backward pass
+  int pw_blocks;
 };
 constexpr int conv_variant(int EPI, int WN, int WK, int NTW, int MT) { return EPI * 10000 + WN * 1000 + WK * 100 + NTW * 10 + MT / 4; }
 #define NINT_MULTI_PROLOGUE                                                                                     \
@@ -742,6 +744,10 @@ __global__ __launch_bounds__(256, 2) void conv_lstm_multi8_kernel(ConvMulti m) {
 }
 template <int DT>
 __global__ __launch_bounds__(256, 3) void conv_bwd_multi_kernel(ConvMulti m) {
+  if (m.pw_blocks && (int)blockIdx.x >= m.begin[m.n]) {      // (nint_seq.wave = 4: the bottom layer's pointwise backward behind the top layer's fused step)
+    lstm_bwd_pointwise_body<DT>(m.pw, blockIdx.x - m.begin[m.n], m.pw_blocks);
+    return;
+  }
   NINT_MULTI_PROLOGUE
   switch (m.variant[i]) {
     NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 4)
@@ -950,7 +956,7 @@ int nint_internal_cell_fwd_plan(const CellFwdJob* j, const nint_geom* g, int dty
 
 // Up to NINT_MULTI_MAX planned launches that do not depend on each other, as ONE grid.  NINT_E_SHAPE (nothing enqueued): one
 // of them has a shape the merged kernels do not hold, or they are of both kinds -- the caller then enqueues them one by one.
-int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream) {
+int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream, const PwArgs* pw) {
   if (!plans || n < 1 || n > NINT_MULTI_MAX) return NINT_E_SHAPE;
   ConvMulti m = {};
   size_t lds = 0;
@@ -965,6 +971,7 @@ int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stre
     if (pl.lds > lds) lds = pl.lds;
   }
   if (nfwd != 0 && nfwd != n) return NINT_E_SHAPE;
+  if (pw && nfwd) return NINT_E_SHAPE;
   m.n = n;
   for (int i = n; i <= NINT_MULTI_MAX; ++i) m.begin[i] = b;
   hipStream_t st = (hipStream_t)stream;
@@ -980,6 +987,16 @@ int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stre
   if (dpair)        // (conv_dgrad_multi8_kernel holds these two shapes only)
     for (int i = 0; i < n; ++i)
       if (plans[i].variant != conv_variant(EPI_DGRAD, 2, 2, 3, 8) && plans[i].variant != conv_variant(EPI_DGRAD, 1, 4, 4, 8)) return NINT_E_SHAPE;
+  if (pw) {                        // (a case of the 4-row backward kernel only)
+    if (rows8 || dpair) return NINT_E_SHAPE;
+    const size_t total = (size_t)pw->N * pw->H * pw->W * (pw->Ch16 / 4);
+    size_t pb = (total + 255) / 256;
+    // as many blocks as the conv problems have workgroups, within [1, 4] items per thread
+    const size_t want = (size_t)b;
+    if (pb > want) pb = want < (pb + 3) / 4 ? (pb + 3) / 4 : want;
+    m.pw = *pw; m.pw_blocks = (int)pb;
+    b += (int)pb;
+  }
   if (dpair) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_dgrad_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_dgrad_multi8_kernel<NINT_F32>) }
   else if (nfwd && rows8) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_F32>) }
   else if (nfwd) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_F32>) }

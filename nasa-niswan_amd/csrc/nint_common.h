@@ -109,6 +109,60 @@ __device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf
 // inf -> rcp 0 -> -1; underflow -> 0 -> rcp(1) -> 1); absolute error ~1e-7 (cancellation near 0 is absolute, not relative)
 __device__ __forceinline__ float tanhf_(float x) { return fmaf(2.0f, rcpf_(1.0f + __expf(-2.0f * x)), -1.0f); }
 
+// LSTM pointwise backward (pointwise.hip: lstm_bwd_pointwise_kernel; also a problem of conv_bwd_multi_kernel, nint_seq.wave = 4):
+// block `blk` of `nblk` 256-thread blocks, grid-stride over (pixel, 4 consecutive hidden channels).
+struct PwArgs {
+  const void* gates; const float* c_prev; const float* c_new; const void* dh; const void* dh2; float* dc; void* dG;
+  int N, H, W, P, Hh, Wh, Ch16, Chp, dc_zero;
+};
+template <int DT>
+__device__ __forceinline__ void lstm_bwd_pointwise_body(const PwArgs& a, size_t blk, size_t nblk) {
+  const int nq = a.Ch16 >> 2;
+  const size_t total = (size_t)a.N * a.H * a.W * nq;
+  const int Gc = 4 * a.Ch16;
+  for (size_t i = blk * 256 + threadIdx.x; i < total; i += nblk * 256) {
+    const int q = i % nq;
+    const size_t pix = i / nq;
+    const int x = pix % a.W;
+    size_t r = pix / a.W;
+    const int y = r % a.H;
+    const int n = r / a.H;
+    const int ch = 4 * q;
+    const int cblock = ch >> 4, col = ch & 15;
+    const size_t gb = pix * Gc + (size_t)cblock * 64 + col;
+    const f32x4_t gi = load_vec4<DT>(a.gates, gb);
+    const f32x4_t gf = load_vec4<DT>(a.gates, gb + 16);
+    const f32x4_t gg = load_vec4<DT>(a.gates, gb + 32);
+    const f32x4_t go = load_vec4<DT>(a.gates, gb + 48);
+    const size_t ci = pix * a.Chp + ch;
+    f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
+    if (a.c_prev) cp = *(const f32x4_t*)(a.c_prev + ci);
+    const f32x4_t cn = *(const f32x4_t*)(a.c_new + ci);
+    f32x4_t dhv = load_vec4<DT>(a.dh, ci);
+    if (a.dh2) dhv += load_vec4<DT>(a.dh2, ci);  // d/dh in two pieces (nint_seq.wave = 4: the x columns of the layer above + the layer's own h columns)
+    f32x4_t dcv = {0.f, 0.f, 0.f, 0.f};
+    if (!a.dc_zero) dcv = *(const f32x4_t*)(a.dc + ci);
+    f32x4_t o_i, o_f, o_g, o_o, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float tc = tanhf_(cn[e]);
+      const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
+      const float d_o = dhv[e] * tc;
+      o_i[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+      o_f[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+      o_g[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+      o_o[e] = d_o * go[e] * (1.f - go[e]);
+      dcp[e] = dct * gf[e];
+    }
+    const size_t ob = ((((size_t)n * a.Hh) + (y + a.P)) * a.Wh + (x + a.P)) * Gc + (size_t)cblock * 64 + col;
+    store_vec4<DT>(a.dG, ob, o_i);
+    store_vec4<DT>(a.dG, ob + 16, o_f);
+    store_vec4<DT>(a.dG, ob + 32, o_g);
+    store_vec4<DT>(a.dG, ob + 48, o_o);
+    *(f32x4_t*)(a.dc + ci) = dcp;
+  }
+}
+
 // launcher-side descriptors -----------------------------------------------------------------
 struct ConvArgs {
   const char* src0;      // halo slab (x for fwd, dG for dgrad)
@@ -166,7 +220,8 @@ struct Probe {
 // internal entry points shared between translation units (not part of the C ABI)
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
-                                     bool dc_zero, void* stream, const void* dh2 = nullptr);   // dh2: a second piece of d/dh, added
+                                     bool dc_zero, void* stream, const void* dh2 = nullptr,    // dh2: a second piece of d/dh, added
+                                     PwArgs* plan = nullptr);                                  // plan: nothing enqueued, *plan describes the launch
 struct WgJob {           // one layer's weight / bias gradient
   const nint_layer* ly; int N;
   const void* dG; const void* x_slab; const void* h_slab;
@@ -220,7 +275,7 @@ struct ConvPlan {
   ConvArgs a; int gx, gy; size_t lds; int variant;   // grid, dynamic LDS, kernel shape (EPI, WN, WK, NTW, MT)
 };
 int nint_internal_cell_fwd_plan(const CellFwdJob* j, const nint_geom* g, int dtype, int N, ConvPlan* plan);
-int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream);
+int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream, const PwArgs* pw = nullptr);   // pw: one more problem, a pointwise backward pass
 struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
   // optional: the layer below's pointwise backward of THIS time step, run on the x columns (the layer's dh buffer is only read)

@@ -555,68 +555,22 @@ extern "C" int nint_pack_weights_layers(const float* const* W, const float* cons
 // (bf16) vector.  (The bias gradient, the column sums of dG, is produced by the weight-gradient kernel, which has the
 // dG fragments in registers anyway: wgrad.hip.)
 template <int DT>
-__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const void* __restrict__ gates, const float* __restrict__ c_prev,
-                                          const float* __restrict__ c_new, const void* __restrict__ dh,
-                                          const void* __restrict__ dh2, float* __restrict__ dc, void* __restrict__ dG,
-                                          int N, int H, int W, int P, int Hh, int Wh, int Ch16, int Chp, int dc_zero) {
-  const int nq = Ch16 >> 2;
-  const size_t total = (size_t)N * H * W * nq;
-  const int Gc = 4 * Ch16;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int q = i % nq;
-    const size_t pix = i / nq;
-    const int x = pix % W;
-    size_t r = pix / W;
-    const int y = r % H;
-    const int n = r / H;
-    const int ch = 4 * q;
-    const int cblock = ch >> 4, col = ch & 15;
-    const size_t gb = pix * Gc + (size_t)cblock * 64 + col;
-    const f32x4_t gi = load_vec4<DT>(gates, gb);
-    const f32x4_t gf = load_vec4<DT>(gates, gb + 16);
-    const f32x4_t gg = load_vec4<DT>(gates, gb + 32);
-    const f32x4_t go = load_vec4<DT>(gates, gb + 48);
-    const size_t ci = pix * Chp + ch;
-    f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
-    if (c_prev) cp = *(const f32x4_t*)(c_prev + ci);
-    const f32x4_t cn = *(const f32x4_t*)(c_new + ci);
-    f32x4_t dhv = load_vec4<DT>(dh, ci);
-    if (dh2) dhv += load_vec4<DT>(dh2, ci);      // d/dh in two pieces (nint_seq.wave = 4: the x columns of the layer above + the layer's own h columns)
-    f32x4_t dcv = {0.f, 0.f, 0.f, 0.f};
-    if (!dc_zero) dcv = *(const f32x4_t*)(dc + ci);
-    f32x4_t o_i, o_f, o_g, o_o, dcp;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float tc = tanhf_(cn[e]);
-      const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
-      const float d_o = dhv[e] * tc;
-      o_i[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
-      o_f[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
-      o_g[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
-      o_o[e] = d_o * go[e] * (1.f - go[e]);
-      dcp[e] = dct * gf[e];
-    }
-    const size_t ob = ((((size_t)n * Hh) + (y + P)) * Wh + (x + P)) * Gc + (size_t)cblock * 64 + col;
-    store_vec4<DT>(dG, ob, o_i);
-    store_vec4<DT>(dG, ob + 16, o_f);
-    store_vec4<DT>(dG, ob + 32, o_g);
-    store_vec4<DT>(dG, ob + 48, o_o);
-    *(f32x4_t*)(dc + ci) = dcp;
-  }
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(PwArgs a) {
+  lstm_bwd_pointwise_body<DT>(a, blockIdx.x, gridDim.x);       // (nint_common.h: the body is also a problem of conv_bwd_multi_kernel)
 }
 
 int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                      const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
-                                     bool dc_zero, void* stream, const void* dh2) {
+                                     bool dc_zero, void* stream, const void* dh2, PwArgs* plan) {
   if (!ly || !g || !gates || !c_new || !dh || !dc || !dG || N <= 0) return NINT_E_ARG;
   if (dtype != NINT_F32 && dtype != NINT_BF16) return NINT_E_ARG;
+  const PwArgs a = {gates, c_prev, c_new, dh, dh2, dc, dG, N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp, dc_zero ? 1 : 0};
+  if (plan) { *plan = a; return NINT_OK; }
   const size_t total = (size_t)N * g->H * g->W * (ly->Ch16 / 4);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid1d(total);
-#define NINT_PW(DT_) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<DT_>), grid, dim3(256), 0, st, gates, c_prev, c_new, dh, dh2, dc, dG, \
-                                        N, g->H, g->W, g->P, g->Hh, g->Wh, ly->Ch16, ly->Chp, dc_zero ? 1 : 0)
-  if (dtype == NINT_BF16) NINT_PW(NINT_BF16); else NINT_PW(NINT_F32);
-#undef NINT_PW
+  if (dtype == NINT_BF16) hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<NINT_BF16>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((lstm_bwd_pointwise_kernel<NINT_F32>), grid, dim3(256), 0, st, a);
   NINT_LAUNCH_CHECK();
   return NINT_OK;
 }
@@ -624,7 +578,7 @@ int nint_internal_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, i
 extern "C" int nint_cell_bwd_pointwise(const nint_layer* ly, const nint_geom* g, int dtype, int N, const void* gates,
                                        const float* c_prev, const float* c_new, const void* dh, float* dc, void* dG,
                                        void* stream) {
-  return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, false, stream, nullptr);
+  return nint_internal_cell_bwd_pointwise(ly, g, dtype, N, gates, c_prev, c_new, dh, dc, dG, false, stream, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------ 1x1 head

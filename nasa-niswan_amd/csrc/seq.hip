@@ -288,10 +288,31 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
     pend.on = false;
     return nint_internal_conv_dgrad(&s->layer[0], g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream);
   };
+  // ... and the bottom layer's pointwise backward of time u waits for the top layer's fused step of time u-1, the next launch in
+  // this order and independent of it (it touches layers >= 1 only): one grid, the fused step's workgroups first (conv_bwd_multi_kernel
+  // with a pointwise problem; the same arithmetic: bit-identical).  B = 2 / 4 / 8: another +1.3 / +0.6 / +0.25 % (profiles/r04_f_wave4.txt).
+  const bool merge_p = merge_d && L >= 3 && fused[L - 1];
+  struct { bool on; int t; } pend_pw = {};
+  auto p0_launch = [&](int t, PwArgs* plan) {
+    const nint_layer* l0 = &s->layer[0];
+    const size_t cs0 = (size_t)B * comp_px * l0->Chp, Gc0 = 4 * (size_t)l0->Ch16;
+    return nint_internal_cell_bwd_pointwise(l0, g, s->dtype, B, (const char*)s->gates[0] + (size_t)t * B * comp_px * Gc0 * es, s->c[0] + (size_t)t * cs0,
+                                            s->c[0] + (size_t)(t + 1) * cs0, s->dh[0], s->dc[0], (char*)s->dG[0] + (size_t)t * B * halo_px * Gc0 * es,
+                                            t == T - 1 && (s->zero_dstate & 1), stream, merge_d && t < T - 1 ? dh0_own : nullptr, plan);
+  };
+  auto flush_pw = [&]() {
+    if (!pend_pw.on) return (int)NINT_OK;
+    pend_pw.on = false;
+    return p0_launch(pend_pw.t, nullptr);
+  };
   for (int so = T - 1; so >= -off[0] && s->bwd_parts != 2; --so) {      // (part 2: the chain ran in the part-1 call)
     for (int l = L - 1; l >= 0; --l) {
       const int u = so + off[l];
       if (u < 0 || u > (fused[l] ? T : T - 1)) continue;
+      if (pend_pw.on && !(l == L - 1 && u >= 1 && u < T)) {     // (anything but the fused step it waits for)
+        rc = flush_pw();
+        if (rc != NINT_OK) return rc;
+      }
       const nint_layer* ly = &s->layer[l];
       const size_t cs = (size_t)B * comp_px * ly->Chp;
       const size_t Gc = 4 * (size_t)ly->Ch16;
@@ -300,6 +321,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       auto pointwise = [&](int t) {      // consumes dh[l] / dc[l] of time t, writes dG of time t
         // first BPTT step: state gradients flagged all-zero are neither read (dc) nor accumulated into (dh below)
         if (!merge_d || l == 0) { const int rf = flush(); if (rf != NINT_OK) return rf; }    // (wave = 4: the held-back launch touches layer 0 only)
+        if (merge_p && l == 0 && so + off[L - 1] >= 2) {     // the next outer step opens with a fused step of the top layer
+          pend_pw.on = true; pend_pw.t = t;
+          return (int)NINT_OK;
+        }
         probe.stamp(NINT_PROBE_POINTWISE, l, t, 0);
         const int r = nint_internal_cell_bwd_pointwise(ly, g, s->dtype, B, (const char*)s->gates[l] + (size_t)t * gs, s->c[l] + (size_t)t * cs,
                                                        s->c[l] + (size_t)(t + 1) * cs, s->dh[l], s->dc[l], (char*)s->dG[l] + (size_t)t * dgs,
@@ -387,6 +412,18 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           rc = flush();
           if (rc != NINT_OK) return rc;
         }
+        if (pend_pw.on) {                        // this fused step and the bottom layer's pointwise backward of the step before: one grid
+          ConvPlan pl;
+          PwArgs pa;
+          rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream, &pl);
+          if (rc == NINT_OK) rc = p0_launch(pend_pw.t, &pa);
+          if (rc != NINT_OK) return rc;
+          rc = pl.gx > 0 ? nint_internal_conv_multi(&pl, 1, s->dtype, stream, &pa) : NINT_E_SHAPE;
+          if (rc == NINT_OK) { pend_pw.on = false; continue; }
+          if (rc != NINT_E_SHAPE) return rc;
+          rc = flush_pw();
+          if (rc != NINT_OK) return rc;
+        }
         probe.stamp(NINT_PROBE_FUSED, l, u, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream);
         probe.stamp(NINT_PROBE_FUSED, l, u, 1);
@@ -402,6 +439,8 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
       if (rc != NINT_OK) return rc;
     }
   }
+  rc = flush_pw();
+  if (rc != NINT_OK) return rc;
   rc = flush();
   if (rc != NINT_OK) return rc;
   // weight / bias gradients: ONE reduction over all T time steps per layer and source, all layers' folds merged
