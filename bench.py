@@ -160,8 +160,8 @@ def parse_args(argv=None):
     ap.add_argument("--fuse-bwd", type=lambda v: int(v, 0), default=0,
                     help="nint_seq.fuse_bwd (BPTT schedule; 0 = the library's per-layer choice, 0x40000000|masks = explicit, see nint.h)")
     ap.add_argument("--wide", type=int, default=0, help="nint_layer.wide of every layer: weight-gradient kernel family (0 = the library's choice, 1 = 4-wave 64-column kernel, 2 = 8-wave 128-column kernel where instantiated)")
-    ap.add_argument("--wave", type=int, default=-1, choices=[-1, 0, 1, 2, 3, 4],
-                    help="merged grids (nint_seq.wave): -1 = the engine's rule by batch size, 0 = off, 1 = forward wavefront + backward pair, 2 = forward wavefront only (8-row tiles), 4 = 2 + the dgrad launches of layers 0 and 1 as one grid")
+    ap.add_argument("--wave", type=int, default=-1, choices=[-1, 0, 1, 2, 3, 4, 5],
+                    help="merged grids (nint_seq.wave): -1 = the engine's rule by batch size, 0 = off, 1 = forward wavefront + backward pair, 2 = forward wavefront only (8-row tiles), 4 = 2 + the BPTT pairs, 5 = the forward pass of 1 + the BPTT pairs of 4")
     ap.add_argument("--tile-rows", type=int, default=0, choices=[0, 1, 2, 4, 8], help="nint_layer.tile_rows of every layer (0 = per launch shape; tiny layers: 1 = stencil gate kernel, 2 = dense-K MFMA gate kernel)")
     ap.add_argument("--overlap-allreduce", action="store_true", help="reduce the gradient bucket in two pieces, all but layer 0's slice under layer 0's weight gradient (FusedTrainer(overlap_allreduce=True))")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path on a 1-GPU box)")
@@ -525,8 +525,8 @@ def main():
         phases = {"step_ms_with_probes": round(float(np.median(step_ms)), 3),
                   "probe_pair_cost_us": round(float(np.mean(dur.get("cal_us", [0.0]))), 2),
                   # with probes on the forward wavefront keeps its merged grids (bracketed as such); the backward pairs of
-                  # nint_seq.wave = 1 / 4 are enqueued as two launches while probes are on
-                  "wave": wave_on, "schedule_differs_from_timed_steps": wave_on in (1, 4),
+                  # nint_seq.wave = 1 / 4 / 5 are enqueued as two launches while probes are on
+                  "wave": wave_on, "schedule_differs_from_timed_steps": wave_on in (1, 4, 5),
                   "per_step_us": {}}
         for key, v in sorted((k, v) for k, v in dur.items() if k != "cal_us"):
             phases["per_step_us"][f"{names[key[0]]}{key[1]}"] = {"launches": len(v) // PSTEPS,

@@ -142,6 +142,8 @@ typedef struct nint_seq {
    *   layer in a stack of three or more, the bottom layer's pointwise backward of time u ALSO waits -- for the top layer's fused
    *   step of time u-1 (the next launch, and independent of it): one grid, the pointwise pass as a problem of the conv kernel
    *   (bit-identical; B = 2 / 4 / 8: another +1.3 / +0.6 / +0.25 %).
+   * wave = 5 (B = 1 at 100 x 154): the forward pass of wave = 1 (every layer on its own tiles) with the BPTT pairs of wave = 4
+   *   (661 against 647 samples/s of wave = 1 and 622 of wave = 4, three fresh-process triples).
    *   (3: wave = 2 plus the backward pair of wave = 1 with the fused step on 8-row tiles: measured +0.2 ... +0.5 %, not used.) */
   int32_t wave;
   /* nint_seq_bwd in two calls, for the data-parallel exchange: 0 = everything in one call; 1 = the BPTT chain and

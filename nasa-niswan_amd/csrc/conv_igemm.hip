@@ -753,6 +753,7 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_multi_kernel(ConvMulti m) {
     NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 4)
     NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 2)
     NINT_MULTI_CASE(EPI_DGRAD, 2, 2, 3)
+    NINT_MULTI_CASE(EPI_DGRAD, 1, 4, 3)
     NINT_MULTI_CASE(EPI_DGRAD_PW, 1, 4, 3)
     default: break;                            // (the register-heavy fused shapes -- 4 column tiles per wave -- would spill at 168 VGPRs)
   }
@@ -788,6 +789,7 @@ static bool multi_holds(int variant) {
     case conv_variant(EPI_LSTM, 4, 1, 4, 4): case conv_variant(EPI_LSTM, 2, 2, 4, 4): case conv_variant(EPI_LSTM, 1, 4, 4, 4):
     case conv_variant(EPI_DGRAD, 1, 4, 4, 4): case conv_variant(EPI_DGRAD, 1, 4, 2, 4): case conv_variant(EPI_DGRAD_PW, 1, 4, 3, 4):
     case conv_variant(EPI_DGRAD, 2, 2, 3, 8): case conv_variant(EPI_DGRAD, 2, 2, 3, 4):      // (8-row: conv_dgrad_multi8_kernel)
+    case conv_variant(EPI_DGRAD, 1, 4, 3, 4):
       return true;
     default: return false;
   }
@@ -983,7 +985,7 @@ int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stre
   for (int i = 0; i < n; ++i) rows8 = rows8 || plans[i].variant % 10 == 2;
   for (int i = 0; i < n; ++i) dpair = dpair || plans[i].variant == conv_variant(EPI_DGRAD, 2, 2, 3, 8);
   for (int i = 0; i < n; ++i)     // (the 4-row form of that shape is a case of conv_bwd_multi_kernel only, not of the 8-row kernel)
-    if (rows8 && plans[i].variant == conv_variant(EPI_DGRAD, 2, 2, 3, 4)) return NINT_E_SHAPE;
+    if (rows8 && (plans[i].variant == conv_variant(EPI_DGRAD, 2, 2, 3, 4) || plans[i].variant == conv_variant(EPI_DGRAD, 1, 4, 3, 4))) return NINT_E_SHAPE;
   if (dpair)        // (conv_dgrad_multi8_kernel holds these two shapes only)
     for (int i = 0; i < n; ++i)
       if (plans[i].variant != conv_variant(EPI_DGRAD, 2, 2, 3, 8) && plans[i].variant != conv_variant(EPI_DGRAD, 1, 4, 4, 8)) return NINT_E_SHAPE;

@@ -280,7 +280,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // pointwise backward adds the two (f32: the same sum as the read-modify-write of the time-major order, bit for bit; bf16: each
   // piece is rounded to bf16 before the f32 add instead of the running sum after it).
   const size_t dh0_bytes = (size_t)B * comp_px * s->layer[0].Chp * es;
-  const bool merge_d = wv == 4 && L >= 2 && !probe.buf && !fused[0] && !fused[1] && !loc[0] && !loc[1] && s->wg_partial_bytes >= dh0_bytes;
+  const bool merge_d = (wv == 4 || wv == 5) && L >= 2 && !probe.buf && !fused[0] && !fused[1] && !loc[0] && !loc[1] && s->wg_partial_bytes >= dh0_bytes;
   void* const dh0_own = merge_d ? s->wg_partial : s->dh[0];
   struct { bool on; ConvPlan plan; const void* dG; void* dx; void* dh_prev; bool ow; } pend = {};
   auto flush = [&]() {                           // the held-back dgrad as a launch of its own

@@ -23,7 +23,7 @@ XFOLD = True
 # nint_layer.wide of engines built afterwards (weight-gradient kernel family): 0 = the library's choice, 1 = always the 4-wave
 # 64-column kernel, 2 = the 8-wave 128-column kernel wherever it is instantiated (tests run both against each other)
 FORCE_WIDE = 0
-FORCE_WAVE = None        # merged grids (nint_seq.wave): None = by batch size (SeqEngine._set_wave), 0 = never, 1 = forward wavefront + backward pair, 2 = forward wavefront only (8-row tiles), 4 = 2 + the dgrad launches of layers 0 and 1 as one grid
+FORCE_WAVE = None        # merged grids (nint_seq.wave): None = by batch size (SeqEngine._set_wave), 0 = never, 1 = forward wavefront + backward pair, 2 = forward wavefront only (8-row tiles), 4 = 2 + the BPTT pairs (dgrad 0 + dgrad 1, pointwise 0 + the top layer's fused step), 5 = the forward pass of 1 + the BPTT pairs of 4
 WAVE_TILES_PER_CU = 1.5   # ... both (4-row / per-shape tiles) while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs: B = 1 at 100 x 154
 WAVE_FWD_TILES_PER_CU = 9 # ... the forward wavefront alone, every layer on 8-row tiles, up to this (B = 2 ... 8 at 100 x 154: 250 ... 1000 tiles on 256 CUs)
 FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
@@ -263,7 +263,9 @@ class SeqEngine:
             # ... and from B = 2 the bottom layer's dgrad rides with layer 1's of the next BPTT step (wave = 4: B = 2 / 4 / 8
             # +3.2 / +1.2 / +0.4 % over wave = 2, every fresh-process pair but one of nine positive; B = 1: 601 against 665 of
             # wave = 1: profiles/r04_f_wave4.txt)
-            mode = 1 if 2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu else (4 if 2 * tiles8 < WAVE_FWD_TILES_PER_CU * self.n_cu else 0)
+            # B = 1: the same BPTT pairs behind the forward wavefront on the layers' own tiles (wave = 5): 661 against 647 (wave = 1)
+            # and 622 (wave = 4) samples/s
+            mode = 5 if 2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu else (4 if 2 * tiles8 < WAVE_FWD_TILES_PER_CU * self.n_cu else 0)
         else:
             mode = int(FORCE_WAVE)
         ws.seq.wave = mode if len(self.cfgs) > 1 else 0

@@ -226,8 +226,8 @@ def test_forward_wavefront_as_one_grid_per_step_changes_no_bit(pkg, shape, dtype
 
 
 def test_forward_wavefront_rule_and_fallback(pkg):
-    """The engine's own rule (FORCE_WAVE None) turns both merged grids on for B = 1 at the bench grid (nint_seq.wave = 1: the
-    same launches as the time-major order, bit for bit) and the forward wavefront alone, EVERY layer on 8-row tiles, for B = 4
+    """The engine's own rule (FORCE_WAVE None) turns the merged grids on for B = 1 at the bench grid (nint_seq.wave = 5: the forward
+    wavefront on the layers' own tiles = the time-major order's launches, bit for bit) and the forward wavefront alone, EVERY layer on 8-row tiles, for B = 4
     and B = 8 (wave = 4, round 4: a two-workgroups-per-CU grid anyway; its backward half is the test below).  That form equals the time-major order bit for bit
     with the tile height pinned to 8, and the default time-major order (4-row tiles for the narrow layers: their four K-slice
     partials are summed in another order) to f32 rounding."""
@@ -238,7 +238,7 @@ def test_forward_wavefront_rule_and_fallback(pkg):
     X1, X4, X8 = (torch.randn(b, 2, 62, 100, 154, device="cuda") for b in (1, 4, 8))
     with torch.no_grad():
         p1, p4, p8 = net(X1), net(X4), net(X8)
-    assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 1, 4: 4, 8: 4}
+    assert {ws.B: ws.seq.wave for pool in net._engine(p1.device).pool.values() for ws in pool} == {1: 5, 4: 4, 8: 4}
     engine.FORCE_WAVE = 0
     try:
         with torch.no_grad():
@@ -263,16 +263,19 @@ def test_forward_wavefront_rule_and_fallback(pkg):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("waves", [(2, 4), (1, 5)])
 @pytest.mark.parametrize("shape", [(7, [24, 16, 8], [5, 3, 3], 2, 1, 5, 37, 50), (62, [64, 32, 16], [5, 3, 3], 20, 4, 3, 100, 154),
                                    (5, [16, 16], [3, 3], 1, 3, 2, 9, 17), (6, [16, 16, 8, 8], [3, 3, 3, 3], 1, 2, 3, 21, 40),
-                                   (62, [64, 32, 16], [5, 3, 3], 20, 8, 2, 100, 154)])
-def test_dgrad_pair_as_one_grid(pkg, shape, dtype):
+                                   (62, [64, 32, 16], [5, 3, 3], 20, 8, 2, 100, 154), (62, [64, 32, 16], [5, 3, 3], 20, 1, 3, 100, 154)])
+def test_dgrad_pair_as_one_grid(pkg, shape, dtype, waves):
     """nint_seq.wave = 4: the bottom layer's dgrad of time u+1 and layer 1's dgrad of time u as ONE grid; each stores its piece of
     the bottom layer's d/dh (the bottom layer's own into the idle split-K scratch) and the pointwise backward adds them.  f32: the
     same f32 sum as the read-modify-write of the time-major order -> every gradient bit for bit.  bf16: the pieces are rounded
     separately -> prediction and the gradients of layers >= 1 bit for bit, layer 0's and the input's to bf16 rounding (measured
-    4.5e-4 / 3e-3 relative at the bench shape).  Reference: wave = 2 (the same forward pass).  With x.requires_grad (dx rides on
-    the bottom dgrad) and on the second pass over a reused workspace."""
+    4.5e-4 / 3e-3 relative at the bench shape).  In a stack of three or more with a fused top layer the bottom layer's pointwise
+    backward also rides with the top layer's fused step of the next BPTT step (the same arithmetic).  Reference: wave = 2 (the same
+    forward pass) for wave = 4, wave = 1 for wave = 5.  With x.requires_grad (dx rides on the bottom dgrad) and on the second pass
+    over a reused workspace."""
     from nasa_niswan_amd import engine
     C, hidden, ks, out, B, T, H, W = shape
     torch.manual_seed(3)
@@ -281,7 +284,7 @@ def test_dgrad_pair_as_one_grid(pkg, shape, dtype):
     res = {}
     old = engine.FORCE_WAVE
     try:
-        for wave in (2, 4):
+        for wave in waves:
             engine.FORCE_WAVE = wave
             torch.manual_seed(4)
             net = pkg.ConvLSTM(C, hidden, ks, len(hidden), out_channels=out, compute_dtype=dtype).cuda()
@@ -295,7 +298,7 @@ def test_dgrad_pair_as_one_grid(pkg, shape, dtype):
             assert {ws.seq.wave for pool in net._engine(X.device).pool.values() for ws in pool} == {wave}
     finally:
         engine.FORCE_WAVE = old
-    for (k, a), (_, b) in zip(res[2], res[4]):
+    for (k, a), (_, b) in zip(res[waves[0]], res[waves[1]]):
         if dtype == "f32" or not (k == "dX" or k.startswith("layers.0.")):
             assert torch.equal(a, b), k
         else:

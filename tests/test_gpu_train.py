@@ -319,7 +319,7 @@ def test_timing_probes_bracket_every_launch_and_change_nothing(pkg):
     """nint_seq.probe (how bench.py prices kernels inside the step): stamp launches around the selected launches of
     nint_seq_fwd / nint_seq_bwd.  They must not change a bit of the step's results, every (kind, layer, t) must appear as a
     begin / end pair in launch order with non-decreasing timestamps, and a step without probes must leave the buffer alone.
-    The forward pass of this small batch is a wavefront of merged grids (nint_seq.wave = 1): those are bracketed as kind 7
+    The forward pass of this small batch is a wavefront of merged grids (nint_seq.wave = 5): those are bracketed as kind 7
     (layer = gate launches in the grid, t = wavefront step), the lone launches at either end as gate launches."""
     import bench
     from nasa_niswan_amd.trainer import FusedTrainer
