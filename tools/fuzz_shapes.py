@@ -75,7 +75,7 @@ def main():
         if args.big:
             H, W, B, T = int(rng.integers(60, 111)), int(rng.integers(100, 171)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
         dtype = "f32" if it % 2 == 0 else "bf16"
-        engine.FORCE_WAVE = [None, 0, 1, 4, 2][it % 5]
+        engine.FORCE_WAVE = [None, 0, 1, 4, 2, 5, 4][it % 7]
         engine.FORCE_TILE_ROWS = [0, 0, 4, 8][it % 4]
         if args.wide:
             engine.FORCE_WIDE = [2, 2, 1][it % 3]
