@@ -131,7 +131,7 @@ typedef struct nint_seq {
    * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
    * not hold (the register-heavy fused shapes, more than 4 layers).  With probes on the forward wavefront is kept (its merged
    * grids are bracketed as NINT_PROBE_WAVE) and the backward pair is enqueued as two launches.
-   * wave = 4 (B = 2 ... 8 at 100 x 154): the forward pass of wave = 2, and in nint_seq_bwd the BOTTOM layer's dgrad of time u+1
+   * wave = 4 (B >= 2 at 100 x 154; B = 12 / 16 / 32: +1 ... +2 % over the time-major order): the forward pass of wave = 2, and in nint_seq_bwd the BOTTOM layer's dgrad of time u+1
    *   waits for layer 1's dgrad of time u: one grid, the wide launch first, so that the narrow layer's workgroups fill its last
    *   round (B = 2 / 4 / 8: +3.2 / +1.2 / +0.4 % on the step, fresh-process pairs, profiles/r04_f_wave4.txt).  Both launches
    *   produce a piece of the bottom layer's d/dh of time u, so each stores its own (layer 1 into dh[0], the bottom layer into the

@@ -24,8 +24,7 @@ XFOLD = True
 # 64-column kernel, 2 = the 8-wave 128-column kernel wherever it is instantiated (tests run both against each other)
 FORCE_WIDE = 0
 FORCE_WAVE = None        # merged grids (nint_seq.wave): None = by batch size (SeqEngine._set_wave), 0 = never, 1 = forward wavefront + backward pair, 2 = forward wavefront only (8-row tiles), 4 = 2 + the BPTT pairs (dgrad 0 + dgrad 1, pointwise 0 + the top layer's fused step), 5 = the forward pass of 1 + the BPTT pairs of 4
-WAVE_TILES_PER_CU = 1.5   # ... both (4-row / per-shape tiles) while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs: B = 1 at 100 x 154
-WAVE_FWD_TILES_PER_CU = 9 # ... the forward wavefront alone, every layer on 8-row tiles, up to this (B = 2 ... 8 at 100 x 154: 250 ... 1000 tiles on 256 CUs)
+WAVE_TILES_PER_CU = 1.5   # ... wave = 5 (the layers' own tiles) while 2 * (8-row pixel tiles of the batch) < WAVE_TILES_PER_CU * CUs: B = 1 at 100 x 154; wave = 4 above
 FUSE_BWD = 0          # nint_seq.fuse_bwd of new workspaces: 0 = per layer, 1 = never fused, 2 = every layer fused (tests run all three)
 
 DTYPES = {"f32": NINT_F32, "fp32": NINT_F32, "float32": NINT_F32, "bf16": NINT_BF16, "bfloat16": NINT_BF16}
@@ -250,9 +249,10 @@ class SeqEngine:
         check(self.lib.nint_seq_fwd(C.byref(ws.seq), st), "nint_seq_fwd")
 
     def _set_wave(self, ws: Workspace):
-        """nint_seq.wave: independent launches (a forward wavefront step; the bottom dgrad with the top layer's fused BPTT
-        step) as one grid.  FORCE_WAVE = None: on for the strong-scaling shapes (up to ~2.5 eight-row pixel tiles per CU:
-        B <= 5 per GPU at 100 x 154; measured +10 / +7 / +2 % at B = 1 / 2 / 4, bimodal at B = 8), 0 / 1: off / on."""
+        """nint_seq.wave: independent launches as one grid (a forward wavefront step; in BPTT the dgrad launches of layers 0 and 1
+        and the bottom pointwise backward with the top layer's fused step).  FORCE_WAVE = None: wave = 5 for the smallest batches
+        (B = 1 at 100 x 154: the layers' own tiles), wave = 4 (every forward layer on 8-row tiles) for everything above;
+        an int: that mode (include/nint.h)."""
         tiles8 = ws.B * ((ws.W + 15) // 16) * ((ws.H + 7) // 8)
         if FORCE_WAVE is None:
             # round 4, six fresh processes per setting at B = 8 (profiles/r04_c_wave_repeats.txt): the forward wavefront as one
@@ -265,7 +265,9 @@ class SeqEngine:
             # wave = 1: profiles/r04_f_wave4.txt)
             # B = 1: the same BPTT pairs behind the forward wavefront on the layers' own tiles (wave = 5): 661 against 647 (wave = 1)
             # and 622 (wave = 4) samples/s
-            mode = 5 if 2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu else (4 if 2 * tiles8 < WAVE_FWD_TILES_PER_CU * self.n_cu else 0)
+            # No upper end: B = 12 / 16 / 32 measure +1.0 ... +2.2 % with wave = 4 against the time-major order (forward -5 %,
+            # backward neutral: profiles/r04_h_big_batches.txt); rounds 3-4 had stopped the rule at B = 8.
+            mode = 5 if 2 * tiles8 < WAVE_TILES_PER_CU * self.n_cu else 4
         else:
             mode = int(FORCE_WAVE)
         ws.seq.wave = mode if len(self.cfgs) > 1 else 0
