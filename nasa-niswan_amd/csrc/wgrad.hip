@@ -589,7 +589,9 @@ __global__ void wgrad_reduce_kernel(ReduceTable t) {
   f32x4_t s = {0.f, 0.f, 0.f, 0.f};
   if (grp < G) {
 #pragma unroll 8
-    for (int sp = grp; sp < splits; sp += G) s += *(const f32x4_t*)(part + i + (size_t)sp * slab);
+    // NON-TEMPORAL: the slabs are read exactly once (in the step: 76 -> 66 us at B = 8, 76 -> 56 us at B = 1, where the fold is 5 % of
+    // the step; the same hint on the weight-gradient kernels' slab STORES costs them more than it saves here: profiles/r04_h_fold_nt.txt)
+    for (int sp = grp; sp < splits; sp += G) s += __builtin_nontemporal_load((const f32x4_t*)(part + i + (size_t)sp * slab));
   }
   red[threadIdx.x] = s;
   __syncthreads();
