@@ -138,12 +138,15 @@ def test_fused_and_classic_schedules_agree(pkg):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
 
 
+@pytest.mark.parametrize("wave", [None, 4, 0])
 @pytest.mark.parametrize("mode", [1, 2, 0x40000404, 0x40000003])
-def test_schedules_with_a_given_initial_state_multi_layer(pkg, mode):
+def test_schedules_with_a_given_initial_state_multi_layer(pkg, mode, wave):
     """nint_seq.has_init_state with fused layers BELOW the top (the combination the model suite only reaches with one
     layer): at u == 0 a fused layer runs the plain dgrad and stores d/dh_init into a dh buffer that, for l < L-1, also
     carried the upper layer's x columns.  Three layers, T = 3, given h0 / c0 per layer; every weight / bias gradient, the input
-    gradient and d/dh_init, d/dc_init of every layer against the oracle's autograd (model.py:253-271 from a given state)."""
+    gradient and d/dh_init, d/dc_init of every layer against the oracle's autograd (model.py:253-271 from a given state).
+    Under the engine's launch schedule for this size (nint_seq.wave = 5: with classic steps in layers 0 and 1 the bottom layer's
+    d/dh travels in two pieces and its d/dh_init must still land in dh[0]), under wave = 4 and in the time-major order."""
     from nasa_niswan_amd import engine
     from nasa_niswan_amd.engine import LayerCfg, SeqEngine
     from oracle import convlstm_oracle as O
@@ -162,7 +165,7 @@ def test_schedules_with_a_given_initial_state_multi_layer(pkg, mode):
     c0o = [t.clone().requires_grad_(True) for t in c0]
     po = O.convlstm_forward(Xo, leaf, h0=h0o, c0=c0o)
     (po * wgt).sum().backward()
-    engine.FUSE_BWD = mode
+    engine.FUSE_BWD, engine.FORCE_WAVE = mode, wave
     try:
         for dtype in ("f32", "bf16"):
             eng = SeqEngine([LayerCfg(Cin if l == 0 else hidden[l - 1], hidden[l], ks[l]) for l in range(L)], dtype, "cuda")
@@ -198,4 +201,4 @@ def test_schedules_with_a_given_initial_state_multi_layer(pkg, mode):
                     r = float((a - b).norm() / (b.norm() + 1e-30))
                     assert r <= 2e-2, (dtype, k, r)
     finally:
-        engine.FUSE_BWD = 0
+        engine.FUSE_BWD, engine.FORCE_WAVE = 0, None
