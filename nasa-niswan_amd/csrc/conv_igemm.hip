@@ -745,7 +745,10 @@ __global__ __launch_bounds__(256, 2) void conv_lstm_multi8_kernel(ConvMulti m) {
 template <int DT>
 __global__ __launch_bounds__(256, 3) void conv_bwd_multi_kernel(ConvMulti m) {
   if (m.pw_blocks && (int)blockIdx.x >= m.begin[m.n]) {      // (nint_seq.wave = 4: the bottom layer's pointwise backward behind the top layer's fused step)
-    lstm_bwd_pointwise_body<DT>(m.pw, blockIdx.x - m.begin[m.n], m.pw_blocks);
+#ifndef NINT_PW_U
+#define NINT_PW_U 2
+#endif
+    lstm_bwd_pointwise_body<DT, NINT_PW_U>(m.pw, blockIdx.x - m.begin[m.n], m.pw_blocks);
     return;
   }
   NINT_MULTI_PROLOGUE

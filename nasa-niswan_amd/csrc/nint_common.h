@@ -115,51 +115,67 @@ struct PwArgs {
   const void* gates; const float* c_prev; const float* c_new; const void* dh; const void* dh2; float* dc; void* dG;
   int N, H, W, P, Hh, Wh, Ch16, Chp, dc_zero;
 };
-template <int DT>
+template <int DT, int U = 1>
 __device__ __forceinline__ void lstm_bwd_pointwise_body(const PwArgs& a, size_t blk, size_t nblk) {
+  // U items per thread and loop turn, all loads of a turn issued before the first store (U = 2 inside conv_bwd_multi_kernel, where
+  // the pass runs at that kernel's occupancy -- 4 workgroups per CU instead of 8 -- and needs the loads in flight per thread instead)
   const int nq = a.Ch16 >> 2;
   const size_t total = (size_t)a.N * a.H * a.W * nq;
   const int Gc = 4 * a.Ch16;
-  for (size_t i = blk * 256 + threadIdx.x; i < total; i += nblk * 256) {
-    const int q = i % nq;
-    const size_t pix = i / nq;
-    const int x = pix % a.W;
-    size_t r = pix / a.W;
-    const int y = r % a.H;
-    const int n = r / a.H;
-    const int ch = 4 * q;
-    const int cblock = ch >> 4, col = ch & 15;
-    const size_t gb = pix * Gc + (size_t)cblock * 64 + col;
-    const f32x4_t gi = load_vec4<DT>(a.gates, gb);
-    const f32x4_t gf = load_vec4<DT>(a.gates, gb + 16);
-    const f32x4_t gg = load_vec4<DT>(a.gates, gb + 32);
-    const f32x4_t go = load_vec4<DT>(a.gates, gb + 48);
-    const size_t ci = pix * a.Chp + ch;
-    f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
-    if (a.c_prev) cp = *(const f32x4_t*)(a.c_prev + ci);
-    const f32x4_t cn = *(const f32x4_t*)(a.c_new + ci);
-    f32x4_t dhv = load_vec4<DT>(a.dh, ci);
-    if (a.dh2) dhv += load_vec4<DT>(a.dh2, ci);  // d/dh in two pieces (nint_seq.wave = 4: the x columns of the layer above + the layer's own h columns)
-    f32x4_t dcv = {0.f, 0.f, 0.f, 0.f};
-    if (!a.dc_zero) dcv = *(const f32x4_t*)(a.dc + ci);
-    f32x4_t o_i, o_f, o_g, o_o, dcp;
+  const size_t stride = nblk * 256;
+  for (size_t i0 = blk * 256 + threadIdx.x; i0 < total; i0 += stride * U) {
+    f32x4_t gi[U], gf[U], gg[U], go[U], cp[U], cn[U], dhv[U], dcv[U];
+    size_t ci[U], ob[U];
+    bool on[U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float tc = tanhf_(cn[e]);
-      const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
-      const float d_o = dhv[e] * tc;
-      o_i[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
-      o_f[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
-      o_g[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
-      o_o[e] = d_o * go[e] * (1.f - go[e]);
-      dcp[e] = dct * gf[e];
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * stride;
+      on[u] = i < total;
+      if (!on[u]) continue;
+      const int q = i % nq;
+      const size_t pix = i / nq;
+      const int x = pix % a.W;
+      size_t r = pix / a.W;
+      const int y = r % a.H;
+      const int n = r / a.H;
+      const int ch = 4 * q;
+      const int cblock = ch >> 4, col = ch & 15;
+      const size_t gb = pix * Gc + (size_t)cblock * 64 + col;
+      gi[u] = load_vec4<DT>(a.gates, gb);
+      gf[u] = load_vec4<DT>(a.gates, gb + 16);
+      gg[u] = load_vec4<DT>(a.gates, gb + 32);
+      go[u] = load_vec4<DT>(a.gates, gb + 48);
+      ci[u] = pix * a.Chp + ch;
+      cp[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (a.c_prev) cp[u] = *(const f32x4_t*)(a.c_prev + ci[u]);
+      cn[u] = *(const f32x4_t*)(a.c_new + ci[u]);
+      dhv[u] = load_vec4<DT>(a.dh, ci[u]);
+      if (a.dh2) dhv[u] += load_vec4<DT>(a.dh2, ci[u]);  // d/dh in two pieces (nint_seq.wave = 4: the x columns of the layer above + the layer's own h columns)
+      dcv[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (!a.dc_zero) dcv[u] = *(const f32x4_t*)(a.dc + ci[u]);
+      ob[u] = ((((size_t)n * a.Hh) + (y + a.P)) * a.Wh + (x + a.P)) * Gc + (size_t)cblock * 64 + col;
     }
-    const size_t ob = ((((size_t)n * a.Hh) + (y + a.P)) * a.Wh + (x + a.P)) * Gc + (size_t)cblock * 64 + col;
-    store_vec4<DT>(a.dG, ob, o_i);
-    store_vec4<DT>(a.dG, ob + 16, o_f);
-    store_vec4<DT>(a.dG, ob + 32, o_g);
-    store_vec4<DT>(a.dG, ob + 48, o_o);
-    *(f32x4_t*)(a.dc + ci) = dcp;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      f32x4_t o_i, o_f, o_g, o_o, dcp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float tc = tanhf_(cn[u][e]);
+        const float dct = dcv[u][e] + dhv[u][e] * go[u][e] * (1.f - tc * tc);
+        const float d_o = dhv[u][e] * tc;
+        o_i[e] = dct * gg[u][e] * gi[u][e] * (1.f - gi[u][e]);
+        o_f[e] = dct * cp[u][e] * gf[u][e] * (1.f - gf[u][e]);
+        o_g[e] = dct * gi[u][e] * (1.f - gg[u][e] * gg[u][e]);
+        o_o[e] = d_o * go[u][e] * (1.f - go[u][e]);
+        dcp[e] = dct * gf[u][e];
+      }
+      store_vec4<DT>(a.dG, ob[u], o_i);
+      store_vec4<DT>(a.dG, ob[u] + 16, o_f);
+      store_vec4<DT>(a.dG, ob[u] + 32, o_g);
+      store_vec4<DT>(a.dG, ob[u] + 48, o_o);
+      *(f32x4_t*)(a.dc + ci[u]) = dcp;
+    }
   }
 }
 
