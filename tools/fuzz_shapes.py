@@ -51,6 +51,27 @@ def check_bias_grad(tag, name, db, dbo, dG_stored, dG_oracle, dtype):
     return float((db - dbo).norm() / (dbo.norm() + 1e-30))
 
 
+def check_head_wgrad(tag, dW, dWo, h_stored, h_oracle, dpred):
+    """The head's weight gradient dW[o][c] = sum_{b,y,x} dpred[b][o][y][x] * h[b][c][y][x] is, with a random-sign dpred, a sum
+    that cancels like the bias gradients (seed 601 #125: 7,772 pixels, |dW| ~ 0.1-0.6, error 5.5e-2 relative under EVERY launch
+    schedule while the prediction is 1.3e-3 off: profiles/r04_h_head_wgrad_case.txt).  Gated on its factors, as check_bias_grad:
+    (1) the REDUCTION: dW equals the f64 sum over the h slab the forward pass STORED, to 1e-5 of the L1 norm of the summands;
+    (2) the SUMMANDS: the stored h against the oracle's (rel-L2 <= 3e-2); (3) what is left against the oracle's dW within the
+    coherent bound 3e-2 * sum |dpred| |h|.  Returns the plain rel-L2 for the log."""
+    dW, dWo = dW.double().reshape(dWo.shape[0], -1), dWo.double().reshape(dWo.shape[0], -1)
+    hs, ho, dp = h_stored.double(), h_oracle.double(), dpred.double()
+    ref = torch.einsum("bohw,bchw->oc", dp, hs)
+    l1s = torch.einsum("bohw,bchw->oc", dp.abs(), hs.abs()) + 1e-30
+    e1 = float(((dW - ref).abs() / l1s).max())
+    assert e1 <= 1e-5, (tag, "head weight gradient is not the sum over the stored h slab", e1)
+    e2 = float((hs - ho).norm() / (ho.norm() + 1e-30))
+    assert e2 <= 3e-2, (tag, "stored h of the top layer against the oracle's", e2)
+    bound = 3e-2 * torch.einsum("bohw,bchw->oc", dp.abs(), ho.abs()) + 1e-30
+    worst = float(((dW - dWo).abs() / bound).max())
+    assert worst <= 1.0, (tag, "head weight gradient outside the coherent-error bound", worst)
+    return float((dW - dWo).norm() / (dWo.norm() + 1e-30))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
@@ -60,6 +81,8 @@ def main():
     ap.add_argument("--dataset", action="store_true", help="the device preproc (z-score, level fusion, cyclic / reflect halo padding) of a resident synthetic record, as a batch tensor and through the model's input slab, against oracle/preproc_oracle.py instead")
     ap.add_argument("--cell", action="store_true", help="ConvLSTMCell(x, h, c) with a given state (forward, all five gradients) against oracle.cell_forward instead")
     ap.add_argument("--trainer", action="store_true", help="FusedTrainer.step (fused head / loss pass, flat gradient bucket) against oracle.train_step instead")
+    ap.add_argument("--only", type=int, default=-1, help="plain module mode: replay the random stream up to this iteration and run it alone, printing every tensor's error")
+    ap.add_argument("--force-wave", type=int, default=None, help="with --only: nint_seq.wave for the replayed case instead of the rotation's value")
     args = ap.parse_args()
     pkg.load_library()
     rng = np.random.default_rng(args.seed)
@@ -83,6 +106,15 @@ def main():
             hidden = [int(rng.choice([32, 64, 64, 128])) if rng.random() < 0.8 else h_ for h_ in hidden]
             ks = [int(rng.choice([3, 3, 5, 7])) if k_ == 1 else k_ for k_ in ks]
             C = int(rng.choice([32, 62, 64, 126, 128])) if rng.random() < 0.7 else C
+        if args.only >= 0:
+            if it < args.only:                   # consume what the case would have drawn: X and the output weights
+                rng.standard_normal((B, T, C, H, W)); rng.standard_normal((B, out, H, W))
+                engine.FORCE_WAVE, engine.FORCE_TILE_ROWS, engine.FORCE_WIDE = None, 0, 0
+                continue
+            if it > args.only:
+                break
+            if args.force_wave is not None:
+                engine.FORCE_WAVE = args.force_wave
         tag = f"#{it} C={C} hidden={hidden} k={ks} out={out} B={B} T={T} {H}x{W} {dtype} wave={engine.FORCE_WAVE} rows={engine.FORCE_TILE_ROWS} wide={engine.FORCE_WIDE}"
         try:
             if args.dataset:
@@ -200,7 +232,7 @@ def main():
             leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
             Xo = X.clone().requires_grad_(True)
             pre = {}
-            po = O.convlstm_forward(Xo, leaf, preact=pre)
+            po, hso, _ = O.convlstm_forward(Xo, leaf, return_states=True, preact=pre)
             (po * wgt).sum().backward()
             res = {"pred": (pred.detach().cpu(), po.detach()), "dX": (Xd.grad.cpu(), Xo.grad)}
             for k, p in net.named_parameters():
@@ -219,9 +251,20 @@ def main():
                     (ws,) = eng.pool[(B, T, H, W, True, False)]
                     check_bias_grad(tag, k, a, b, stored_dG(eng, ws, l).cpu(), torch.cat([pre[(l, t)].grad for t in range(T)]), dtype)
                     continue
+                elif k == "grad.conv.weight":
+                    # the head's weight gradient: a sum over pixels with random signs (check_head_wgrad)
+                    eng = net._engine(Xd.device)
+                    (ws,) = eng.pool[(B, T, H, W, True, False)]
+                    e = check_head_wgrad(tag, a, b, eng.h_last(ws, L - 1).cpu(), hso[-1].detach(), wgt)
+                    if args.only >= 0:
+                        print(f"     {k}: rel-L2 {e:.3e} (gated on its factors)", flush=True)
                 else:
                     e = float((a - b).norm() / (b.norm() + 1e-30))
-                    assert e <= 3e-2, (tag, k, e)
+                    if args.only >= 0:
+                        print(f"     {k}: rel-L2 {e:.3e}  |ref| {float(b.norm()):.3e}", flush=True)
+                        if k == "grad.conv.weight":
+                            print("       hip   ", a.flatten().tolist()); print("       oracle", b.flatten().tolist())
+                    assert e <= 3e-2 or args.only >= 0, (tag, k, e)
                 w = max(w, e)
             worst[dtype] = max(worst[dtype], w)
             print(f"ok   {tag}  worst {w:.2e}", flush=True)
