@@ -45,7 +45,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
 XGMI_LINK_GBS = 153.0          # per-link, per direction (task statement: 7 links x ~153 GB/s per GPU)
-PROBE_GATE, PROBE_POINTWISE, PROBE_DGRAD, PROBE_FUSED, PROBE_WGRAD, PROBE_FOLD, PROBE_WAVE = 1, 2, 3, 4, 5, 6, 7   # include/nint.h NINT_PROBE_*
+PROBE_GATE, PROBE_POINTWISE, PROBE_DGRAD, PROBE_FUSED, PROBE_WGRAD, PROBE_FOLD, PROBE_WAVE, PROBE_BWD_PAIR, PROBE_BWD_PW = 1, 2, 3, 4, 5, 6, 7, 8, 9   # include/nint.h NINT_PROBE_*
 
 
 def fwd_flops_per_sample(C, hidden, ks, out, T, Hp, Wp):
@@ -386,7 +386,7 @@ def main():
         # probe pass: PSTEPS more steps with stamps around the layer-0 gate / dgrad / pointwise launches, every layer's
         # weight-gradient block and the fold.  EVERY rank runs the steps (each ends in the all-reduce); rank 0 alone stamps.
         pbuf = torch.zeros(2 * SLOTS, dtype=torch.int64, device=dev) if rank == 0 else None
-        mask = (1 << PROBE_GATE) | (1 << PROBE_POINTWISE) | (1 << PROBE_DGRAD) | (1 << PROBE_FUSED) | (1 << PROBE_WGRAD) | (1 << PROBE_FOLD) | (1 << PROBE_WAVE)
+        mask = (1 << PROBE_GATE) | (1 << PROBE_POINTWISE) | (1 << PROBE_DGRAD) | (1 << PROBE_FUSED) | (1 << PROBE_WGRAD) | (1 << PROBE_FOLD) | (1 << PROBE_WAVE) | (1 << PROBE_BWD_PAIR) | (1 << PROBE_BWD_PW)
         st_ = torch.cuda.current_stream()
 
         def ev_timer():
@@ -477,6 +477,7 @@ def main():
         us_pw, n_pw = mean_us(PROBE_POINTWISE, 0)
         us_wg, _ = mean_us(PROBE_WGRAD, 0)
         us_fold, _ = mean_us(PROBE_FOLD, 0)
+        us_pair, _ = mean_us(PROBE_BWD_PAIR, 1)          # BPTT grid 1 (nint_seq.wave = 4 / 5): layer-0 dgrad of u+1 + layer-1 dgrad of u
         ms_ = lambda us: None if us is None else us * 1e-3
         gate_loop = time_kernel(k_fwd, 50, st)
         roof_gate = entry("conv_igemm_fwd_layer0", "layer-0 gate kernel, LSTM epilogue (B images, one time step, full K)", "mfma",
@@ -514,19 +515,22 @@ def main():
                        note=f"loop figure = the stand-alone entry (all T steps of both sources + the fold, {wg_loop:.3f} ms) scaled by the executed / nominal FLOPs"),
                  launches_per_step=1),
             dict(entry("conv_igemm_dgrad_layer0", "layer-0 dgrad kernel (h columns; B images, one time step)",
-                       "mfma", f_dgrad, ms_(us_dgrad), time_kernel(k_dgrad, 50, st)), launches_per_step=n_dgrad or T - 1),
+                       "mfma", f_dgrad, ms_(us_dgrad), time_kernel(k_dgrad, 50, st),
+                       note=None if us_dgrad is not None or us_pair is None else
+                       f"in the timed steps this launch is one half of a merged BPTT grid ({us_pair:.1f} us together with layer 1's dgrad: phases.per_step_us); priced in a warm loop"),
+                 launches_per_step=n_dgrad or T - 1),
             dict(entry("lstm_bwd_pointwise_layer0", "lstm_bwd_pointwise_kernel layer 0 (B images, one time step)", "hbm",
                        b_pw, ms_(us_pw), time_kernel(k_pw, 50, st)), launches_per_step=n_pw or T),
         ]
         eng.release(ws)
         # per (kind, layer) in-step totals: what the step spends where (microseconds per step)
         names = {PROBE_GATE: "gate", PROBE_POINTWISE: "pointwise", PROBE_DGRAD: "dgrad", PROBE_FUSED: "fused_bptt_step",
-                 PROBE_WGRAD: "wgrad", PROBE_FOLD: "fold", PROBE_WAVE: "fwd_wavefront_grid_of_"}
+                 PROBE_WGRAD: "wgrad", PROBE_FOLD: "fold", PROBE_WAVE: "fwd_wavefront_grid_of_",
+                 PROBE_BWD_PAIR: "bptt_grid_dgrad0_with_launch_of_layer", PROBE_BWD_PW: "bptt_grid_pointwise0_with_fused_step_of_layer"}
         phases = {"step_ms_with_probes": round(float(np.median(step_ms)), 3),
                   "probe_pair_cost_us": round(float(np.mean(dur.get("cal_us", [0.0]))), 2),
-                  # with probes on the forward wavefront keeps its merged grids (bracketed as such); the backward pairs of
-                  # nint_seq.wave = 1 / 4 / 5 are enqueued as two launches while probes are on
-                  "wave": wave_on, "schedule_differs_from_timed_steps": wave_on in (1, 4, 5),
+                  # probes do not change the schedule: merged grids are bracketed as such (kinds 7, 8, 9)
+                  "wave": wave_on, "schedule_differs_from_timed_steps": False,
                   "per_step_us": {}}
         for key, v in sorted((k, v) for k, v in dur.items() if k != "cal_us"):
             phases["per_step_us"][f"{names[key[0]]}{key[1]}"] = {"launches": len(v) // PSTEPS,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NINT_VERSION 110
+#define NINT_VERSION 111
 
 enum { NINT_F32 = 0, NINT_BF16 = 1 };
 
@@ -129,8 +129,8 @@ typedef struct nint_seq {
    *   nint_seq_bwd enqueues the bottom layer's dgrad of one BPTT step together with the top layer's fused step of the next
    *     (adjacent launches that share no buffer in a stack of three or more layers).
    * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
-   * not hold (the register-heavy fused shapes, more than 4 layers).  With probes on the forward wavefront is kept (its merged
-   * grids are bracketed as NINT_PROBE_WAVE) and the backward pair is enqueued as two launches.
+   * not hold (the register-heavy fused shapes, more than 4 layers).  Probes do not change the schedule: merged grids are
+   * bracketed as such (NINT_PROBE_WAVE, NINT_PROBE_BWD_PAIR, NINT_PROBE_BWD_PW).
    * wave = 4 (B >= 2 at 100 x 154; B = 12 / 16 / 32: +1 ... +2 % over the time-major order): the forward pass of wave = 2, and in nint_seq_bwd the BOTTOM layer's dgrad of time u+1
    *   waits for layer 1's dgrad of time u: one grid, the wide launch first, so that the narrow layer's workgroups fill its last
    *   round (B = 2 / 4 / 8: +3.2 / +1.2 / +0.4 % on the step, fresh-process pairs, profiles/r04_f_wave4.txt).  Both launches
@@ -138,7 +138,7 @@ typedef struct nint_seq {
    *   head of wg_partial, which is idle until the weight gradients) and the bottom layer's pointwise backward adds the two:
    *   f32 = the time-major order bit for bit (the same f32 sum); bf16: each piece is rounded to bf16 before the f32 add instead
    *   of the running sum after it (layer 0's gradients move by ~1e-3 relative).  Needs wg_partial_bytes >= B*H*W*Chp[0]*es,
-   *   classic (unfused) steps in layers 0 and 1, and no probes; otherwise the launches go out one by one.  With a fused top
+   *   classic (unfused) steps in layers 0 and 1; otherwise the launches go out one by one.  With a fused top
    *   layer in a stack of three or more, the bottom layer's pointwise backward of time u ALSO waits -- for the top layer's fused
    *   step of time u-1 (the next launch, and independent of it): one grid, the pointwise pass as a problem of the conv kernel
    *   (bit-identical; B = 2 / 4 / 8: another +1.3 / +0.6 / +0.25 %).
@@ -157,7 +157,11 @@ typedef struct nint_seq {
 /* launch kinds for nint_seq.probe_mask / the probe tags */
 enum { NINT_PROBE_CAL = 0, NINT_PROBE_GATE = 1, NINT_PROBE_POINTWISE = 2, NINT_PROBE_DGRAD = 3, NINT_PROBE_FUSED = 4,
        NINT_PROBE_WGRAD = 5, NINT_PROBE_FOLD = 6,
-       NINT_PROBE_WAVE = 7 /* a merged forward grid (nint_seq.wave): tag layer = number of gate launches in it, t = wavefront step */ };
+       NINT_PROBE_WAVE = 7, /* a merged forward grid (nint_seq.wave): tag layer = number of gate launches in it, t = wavefront step */
+       NINT_PROBE_BWD_PAIR = 8, /* a merged BPTT grid of two conv launches (wave = 4 / 5: the dgrad launches of layers 0 and 1; wave = 1 / 3:
+                                 * the bottom dgrad with the top layer's fused step): tag layer = the second launch's layer, t = its time step */
+       NINT_PROBE_BWD_PW = 9    /* wave = 4 / 5: the top layer's fused step with the bottom layer's pointwise backward: tag layer = the
+                                 * fused layer, t = its time step */ };
 
 /* ---- library / device ---------------------------------------------------------------- */
 int nint_version(void);

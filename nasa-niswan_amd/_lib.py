@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libnint_hip.so")     # the one product library; n
 NINT_F32, NINT_BF16 = 0, 1
 NINT_OK, NINT_E_ARG, NINT_E_SHAPE, NINT_E_LDS, NINT_E_ALIGN = 0, -1, -2, -3, -4
 NINT_MAX_LAYERS = 8
-NINT_VERSION = 110     # include/nint.h NINT_VERSION: the library this binding was written against
+NINT_VERSION = 111     # include/nint.h NINT_VERSION: the library this binding was written against
 NINT_LOSS_SCRATCH_FLOATS = 8194
 NINT_LOSS_STATS = 8
 

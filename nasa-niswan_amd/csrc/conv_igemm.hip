@@ -961,7 +961,7 @@ int nint_internal_cell_fwd_plan(const CellFwdJob* j, const nint_geom* g, int dty
 
 // Up to NINT_MULTI_MAX planned launches that do not depend on each other, as ONE grid.  NINT_E_SHAPE (nothing enqueued): one
 // of them has a shape the merged kernels do not hold, or they are of both kinds -- the caller then enqueues them one by one.
-int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream, const PwArgs* pw) {
+int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream, const PwArgs* pw, bool dry_run) {
   if (!plans || n < 1 || n > NINT_MULTI_MAX) return NINT_E_SHAPE;
   ConvMulti m = {};
   size_t lds = 0;
@@ -1002,6 +1002,7 @@ int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stre
     m.pw = *pw; m.pw_blocks = (int)pb;
     b += (int)pb;
   }
+  if (dry_run) return NINT_OK;     // (the caller only asked whether these launches go into one grid)
   if (dpair) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_dgrad_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_dgrad_multi8_kernel<NINT_F32>) }
   else if (nfwd && rows8) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi8_kernel<NINT_F32>) }
   else if (nfwd) { if (dtype == NINT_BF16) NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_BF16>) else NINT_MULTI_LAUNCH(conv_lstm_multi_kernel<NINT_F32>) }

@@ -291,7 +291,8 @@ struct ConvPlan {
   ConvArgs a; int gx, gy; size_t lds; int variant;   // grid, dynamic LDS, kernel shape (EPI, WN, WK, NTW, MT)
 };
 int nint_internal_cell_fwd_plan(const CellFwdJob* j, const nint_geom* g, int dtype, int N, ConvPlan* plan);
-int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream, const PwArgs* pw = nullptr);   // pw: one more problem, a pointwise backward pass
+int nint_internal_conv_multi(const ConvPlan* plans, int n, int dtype, void* stream, const PwArgs* pw = nullptr,    // pw: one more problem, a pointwise backward pass
+                             bool dry_run = false);                                                          // dry_run: NINT_OK / NINT_E_SHAPE, nothing enqueued
 struct DgradPw {         // fused pointwise backward of the previous time step (EPI_DGRAD_PW)
   const void* gates; const float* c_prev; const float* c_new; float* dc; const void* old; void* dG_out;
   // optional: the layer below's pointwise backward of THIS time step, run on the x columns (the layer's dh buffer is only read)

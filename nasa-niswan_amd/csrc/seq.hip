@@ -272,7 +272,7 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // state and layer L-2's; the bottom dgrad reads dG[0] and writes dh[0] / dx): they go out as ONE grid
   // (nint_internal_conv_multi).  The bottom dgrad is held back (`pend`) until the next launch is known.
   const int wv = s->wave;
-  const bool merge = (wv == 1 || wv == 3) && L >= 3 && !probe.buf && fused[L - 1] && !fused[0] && !loc[0];   // (wave == 2: the forward wavefront only)
+  const bool merge = (wv == 1 || wv == 3) && L >= 3 && fused[L - 1] && !fused[0] && !loc[0];   // (wave == 2: the forward wavefront only)
   // Mid-size batches (wave = 4): the bottom layer's dgrad of time u+1 waits for the dgrad of the layer above of time u instead and
   // the two go out as one grid, the wide one first (the narrow layer's workgroups fill its last round: the forward wavefront's
   // effect).  Both produce a piece of the bottom layer's d/dh of time u, so each stores its own -- the layer above into dh[0],
@@ -280,13 +280,16 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   // pointwise backward adds the two (f32: the same sum as the read-modify-write of the time-major order, bit for bit; bf16: each
   // piece is rounded to bf16 before the f32 add instead of the running sum after it).
   const size_t dh0_bytes = (size_t)B * comp_px * s->layer[0].Chp * es;
-  const bool merge_d = (wv == 4 || wv == 5) && L >= 2 && !probe.buf && !fused[0] && !fused[1] && !loc[0] && !loc[1] && s->wg_partial_bytes >= dh0_bytes;
+  const bool merge_d = (wv == 4 || wv == 5) && L >= 2 && !fused[0] && !fused[1] && !loc[0] && !loc[1] && s->wg_partial_bytes >= dh0_bytes;
   void* const dh0_own = merge_d ? s->wg_partial : s->dh[0];
-  struct { bool on; ConvPlan plan; const void* dG; void* dx; void* dh_prev; bool ow; } pend = {};
+  struct { bool on; ConvPlan plan; const void* dG; void* dx; void* dh_prev; bool ow; int u; } pend = {};
   auto flush = [&]() {                           // the held-back dgrad as a launch of its own
     if (!pend.on) return (int)NINT_OK;
     pend.on = false;
-    return nint_internal_conv_dgrad(&s->layer[0], g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream);
+    probe.stamp(NINT_PROBE_DGRAD, 0, pend.u, 0);
+    const int r = nint_internal_conv_dgrad(&s->layer[0], g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream);
+    probe.stamp(NINT_PROBE_DGRAD, 0, pend.u, 1);
+    return r;
   };
   // ... and the bottom layer's pointwise backward of time u waits for the top layer's fused step of time u-1, the next launch in
   // this order and independent of it (it touches layers >= 1 only): one grid, the fused step's workgroups first (conv_bwd_multi_kernel
@@ -303,7 +306,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
   auto flush_pw = [&]() {
     if (!pend_pw.on) return (int)NINT_OK;
     pend_pw.on = false;
-    return p0_launch(pend_pw.t, nullptr);
+    probe.stamp(NINT_PROBE_POINTWISE, 0, pend_pw.t, 0);
+    const int r = p0_launch(pend_pw.t, nullptr);
+    probe.stamp(NINT_PROBE_POINTWISE, 0, pend_pw.t, 1);
+    return r;
   };
   for (int so = T - 1; so >= -off[0] && s->bwd_parts != 2; --so) {      // (part 2: the chain ran in the part-1 call)
     for (int l = L - 1; l >= 0; --l) {
@@ -363,7 +369,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           pl[0] = pend.plan;
           rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, nullptr, stream, &pl[1]);
           if (rc != NINT_OK) return rc;
-          rc = pl[1].gx > 0 ? nint_internal_conv_multi(pl, 2, s->dtype, stream) : NINT_E_SHAPE;
+          rc = pl[1].gx > 0 ? nint_internal_conv_multi(pl, 2, s->dtype, stream, nullptr, true) : NINT_E_SHAPE;     // (dry run: is there such a grid?)
+          if (rc == NINT_OK) {
+            probe.stamp(NINT_PROBE_BWD_PAIR, l, u, 0);
+            rc = nint_internal_conv_multi(pl, 2, s->dtype, stream);
+            probe.stamp(NINT_PROBE_BWD_PAIR, l, u, 1);
+          }
           if (rc == NINT_OK) { pend.on = false; continue; }
           if (rc != NINT_E_SHAPE) return rc;
         }
@@ -372,15 +383,18 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           if (rc != NINT_OK) return rc;
         }
         if ((merge || merge_d) && l == 0 && so > -off[0]) {  // (not the very last launch: there is a top-layer step to pair it with)
-          pend.dG = (const char*)s->dG[l] + (size_t)u * dgs; pend.dx = dx_dst; pend.dh_prev = dh_prev; pend.ow = ow;
+          pend.dG = (const char*)s->dG[l] + (size_t)u * dgs; pend.dx = dx_dst; pend.dh_prev = dh_prev; pend.ow = ow; pend.u = u;
           rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, pend.dG, pend.dx, pend.dh_prev, pend.ow, nullptr, stream, &pend.plan);
           if (rc != NINT_OK) return rc;
           pend.on = pend.plan.gx > 0;
           continue;
         }
-        probe.stamp(NINT_PROBE_DGRAD, l, u, 0);
+        // (time 0 of the bottom layer from a zero state without an input gradient: nothing to launch -- and nothing to bracket: rounds
+        // 3-4 stamped this empty call, one zero among the 12 layer-0 dgrad durations of a step)
+        const bool nop = !dx_dst && !dh_prev && !loc[l];
+        if (!nop) probe.stamp(NINT_PROBE_DGRAD, l, u, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, dh_prev, ow, loc[l] ? &pw : nullptr, stream);
-        probe.stamp(NINT_PROBE_DGRAD, l, u, 1);
+        if (!nop) probe.stamp(NINT_PROBE_DGRAD, l, u, 1);
       } else if (u == T) {
         rc = pointwise(T - 1);
       } else if (u >= 1) {
@@ -404,7 +418,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           if (s->wave == 3) pw.tile_rows = 8;    // (experiment: the fused step on 8-row tiles inside the two-workgroups-per-CU grid)
           rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream, &pl[1]);
           if (rc != NINT_OK) return rc;
-          rc = pl[1].gx > 0 ? nint_internal_conv_multi(pl, 2, s->dtype, stream) : NINT_E_SHAPE;
+          rc = pl[1].gx > 0 ? nint_internal_conv_multi(pl, 2, s->dtype, stream, nullptr, true) : NINT_E_SHAPE;     // (dry run: is there such a grid?)
+          if (rc == NINT_OK) {
+            probe.stamp(NINT_PROBE_BWD_PAIR, l, u, 0);
+            rc = nint_internal_conv_multi(pl, 2, s->dtype, stream);
+            probe.stamp(NINT_PROBE_BWD_PAIR, l, u, 1);
+          }
           if (rc == NINT_OK) { pend.on = false; continue; }
           if (rc != NINT_E_SHAPE) return rc;
         }
@@ -418,7 +437,12 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l] + (size_t)u * dgs, dx_dst, nullptr, ow, &pw, stream, &pl);
           if (rc == NINT_OK) rc = p0_launch(pend_pw.t, &pa);
           if (rc != NINT_OK) return rc;
-          rc = pl.gx > 0 ? nint_internal_conv_multi(&pl, 1, s->dtype, stream, &pa) : NINT_E_SHAPE;
+          rc = pl.gx > 0 ? nint_internal_conv_multi(&pl, 1, s->dtype, stream, &pa, true) : NINT_E_SHAPE;
+          if (rc == NINT_OK) {
+            probe.stamp(NINT_PROBE_BWD_PW, l, u, 0);
+            rc = nint_internal_conv_multi(&pl, 1, s->dtype, stream, &pa);
+            probe.stamp(NINT_PROBE_BWD_PW, l, u, 1);
+          }
           if (rc == NINT_OK) { pend_pw.on = false; continue; }
           if (rc != NINT_E_SHAPE) return rc;
           rc = flush_pw();
@@ -432,9 +456,10 @@ extern "C" int nint_seq_bwd(const nint_seq* s, void* stream) {
           rc = flush();
           if (rc != NINT_OK) return rc;
         }
-        probe.stamp(NINT_PROBE_DGRAD, l, 0, 0);
+        const bool nop = !dx_dst && !dh_prev;
+        if (!nop) probe.stamp(NINT_PROBE_DGRAD, l, 0, 0);
         rc = nint_internal_conv_dgrad(ly, g, s->dtype, B, (const char*)s->dG[l], dx_dst, dh_prev, ow, nullptr, stream);
-        probe.stamp(NINT_PROBE_DGRAD, l, 0, 1);
+        if (!nop) probe.stamp(NINT_PROBE_DGRAD, l, 0, 1);
       }
       if (rc != NINT_OK) return rc;
     }

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in nint.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.nint_version() == _lib.NINT_VERSION == 110
+    assert lib.nint_version() == _lib.NINT_VERSION == 111
     assert lib.nint_kc(0) == 16 and lib.nint_kc(1) == 32
     assert lib.nint_error_string(-2).decode().startswith("nint:")
 
