@@ -117,34 +117,33 @@ typedef struct nint_seq {
                                         * fills slots from 0, nint_seq_bwd from probe_slots / 2; each starts with two back-to-back
                                         * calibration stamps (kind 0).  tag = kind | layer << 8 | t << 16 | end << 31 */
   int32_t probe_slots;
-  /* Independent launches as ONE grid, for the strong-scaling shapes (B <= ~5 per GPU at 100 x 154), where one layer's launch
-   * does not fill 256 CUs.  wave = 1: both of the following; wave = 2: the forward wavefront only, every layer of the merged grid on
-   * 8-row tiles (mid-size batches -- B = 8 at 100 x 154 -- where the forward merge measured -3.4 % on the forward pass in every
-   * fresh process, another -5 % with the narrow layers on 8-row tiles, and the backward pair neutral with an occasional slow
-   * process: profiles/r04_c_wave_repeats.txt, r04_d_wave_rows8.txt; results = the time-major order's with tile_rows pinned to 8
-   * bit for bit, the default time-major order's to f32 rounding); 0: neither.
-   *   nint_seq_fwd runs the (t, layer) wavefront (model.py:265-271: gate(l, t) needs gate(l-1, t) and gate(l, t-1) only, so
-   *     gate(0, t+1), gate(1, t), gate(2, t-1) are independent): each wavefront step is one grid holding the workgroups of
-   *     all its gate launches (T + L - 1 launches instead of T * L);
-   *   nint_seq_bwd enqueues the bottom layer's dgrad of one BPTT step together with the top layer's fused step of the next
-   *     (adjacent launches that share no buffer in a stack of three or more layers).
-   * Same workgroups on the same data: bit-identical results.  Falls back to one launch each for shapes the merged kernels do
-   * not hold (the register-heavy fused shapes, more than 4 layers).  Probes do not change the schedule: merged grids are
-   * bracketed as such (NINT_PROBE_WAVE, NINT_PROBE_BWD_PAIR, NINT_PROBE_BWD_PW).
-   * wave = 4 (B >= 2 at 100 x 154; B = 12 / 16 / 32: +1 ... +2 % over the time-major order): the forward pass of wave = 2, and in nint_seq_bwd the BOTTOM layer's dgrad of time u+1
-   *   waits for layer 1's dgrad of time u: one grid, the wide launch first, so that the narrow layer's workgroups fill its last
-   *   round (B = 2 / 4 / 8: +3.2 / +1.2 / +0.4 % on the step, fresh-process pairs, profiles/r04_f_wave4.txt).  Both launches
-   *   produce a piece of the bottom layer's d/dh of time u, so each stores its own (layer 1 into dh[0], the bottom layer into the
-   *   head of wg_partial, which is idle until the weight gradients) and the bottom layer's pointwise backward adds the two:
-   *   f32 = the time-major order bit for bit (the same f32 sum); bf16: each piece is rounded to bf16 before the f32 add instead
-   *   of the running sum after it (layer 0's gradients move by ~1e-3 relative).  Needs wg_partial_bytes >= B*H*W*Chp[0]*es,
-   *   classic (unfused) steps in layers 0 and 1; otherwise the launches go out one by one.  With a fused top
-   *   layer in a stack of three or more, the bottom layer's pointwise backward of time u ALSO waits -- for the top layer's fused
-   *   step of time u-1 (the next launch, and independent of it): one grid, the pointwise pass as a problem of the conv kernel
-   *   (bit-identical; B = 2 / 4 / 8: another +1.3 / +0.6 / +0.25 %).
-   * wave = 5 (B = 1 at 100 x 154): the forward pass of wave = 1 (every layer on its own tiles) with the BPTT pairs of wave = 4
-   *   (661 against 647 samples/s of wave = 1 and 622 of wave = 4, three fresh-process triples).
-   *   (3: wave = 2 plus the backward pair of wave = 1 with the fused step on 8-row tiles: measured +0.2 ... +0.5 %, not used.) */
+  /* Independent launches as ONE grid (csrc/conv_igemm.hip: conv_lstm_multi[8]_kernel, conv_bwd_multi[8]_kernel,
+   * conv_dgrad_multi8_kernel; every problem of a grid runs the body its own launch would have run).
+   *   0  every launch by itself, time-major order (for t: for layer).
+   *   1  forward: the (t, layer) wavefront (model.py:265-271: gate(l, t) needs gate(l-1, t) and gate(l, t-1) only, so gate(0, t+1),
+   *      gate(1, t), gate(2, t-1) are independent) -- each wavefront step is one grid, T + L - 1 launches instead of T * L, every
+   *      layer on the tiles its own launch takes; BPTT: the bottom layer's dgrad of one step with the top layer's fused step of
+   *      the next (adjacent launches that share no buffer in a stack of three or more layers).  Bit-identical to 0.
+   *   2  the forward wavefront only, every layer of a grid on 8-row tiles (the first layer's tile makes the grid a two-workgroups-
+   *      per-CU kernel anyway; half the weight bytes per MFMA for the narrow layers: forward pass -5 % at B = 8,
+   *      profiles/r04_c_wave_repeats.txt, r04_d_wave_rows8.txt).  = the time-major order with tile_rows pinned to 8 bit for bit, the
+   *      default time-major order (4-row narrow tiles: another order of the K-slice partials) to f32 rounding.
+   *   3  2 + the BPTT pair of 1 with the fused step on 8-row tiles (measured +0.2 ... +0.5 %; not used).
+   *   4  the forward pass of 2; BPTT as TWO grids per step (profiles/r04_f_wave4.txt):
+   *      (a) the bottom layer's dgrad of time u+1 waits for layer 1's dgrad of time u: one grid, the wide launch first, so that
+   *          the narrow layer's workgroups fill its last round.  Both produce a piece of the bottom layer's d/dh of time u; each
+   *          stores its own (layer 1 into dh[0], the bottom layer into the head of wg_partial, idle until the weight gradients)
+   *          and the bottom layer's pointwise backward adds the two: f32 = the time-major order bit for bit (the same f32 sum);
+   *          bf16: each piece is rounded before the f32 add instead of the running sum after it (layer 0's gradients move by
+   *          ~1e-3 relative).  Needs wg_partial_bytes >= B*H*W*Chp[0]*es and classic (unfused) steps in layers 0 and 1;
+   *      (b) with a fused top layer in a stack of three or more, the bottom layer's pointwise backward of time u waits for the
+   *          top layer's fused step of time u-1 (the next launch, touching layers >= 1 only): one grid, the pointwise pass as a
+   *          problem of the conv kernel (the same arithmetic: bit-identical).
+   *      B = 2 / 4 / 8 at 100 x 154: +4.5 / +1.8 / +0.65 % over 2; B = 12 / 16 / 32: +1 ... +2 % over 0.
+   *   5  the forward pass of 1 with the BPTT of 4 (B = 1 at 100 x 154: 661 against 647 samples/s of 1 and 622 of 4).
+   * A shape the merged kernels do not hold (register-heavy fused shapes, more than 4 layers, launch shapes without a case) goes out
+   * as separate launches.  Probes do not change the schedule: merged grids are bracketed as such (NINT_PROBE_WAVE,
+   * NINT_PROBE_BWD_PAIR, NINT_PROBE_BWD_PW).  SeqEngine picks 5 for the smallest batches and 4 above (engine.py:_set_wave). */
   int32_t wave;
   /* nint_seq_bwd in two calls, for the data-parallel exchange: 0 = everything in one call; 1 = the BPTT chain and
    * the weight / bias gradients of layers >= 1 (their fold included); 2 = the weight / bias gradient of layer 0 only (dG[0] of
